@@ -1,0 +1,2 @@
+/* gguf_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE). Filled in below. */
+#include "bitnet_oracle.h"

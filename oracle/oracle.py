@@ -1,0 +1,315 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Nothing under bitnet-rs_amd/ does.  See bitnet_oracle.h for what
+each function restates (reference file:line).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbitnet_oracle.so")
+REF_LIB_PATH = os.path.join(HERE, "_ref", "libggml_iq2s_ref.so")
+ERRLEN = 256
+
+_u8p = C.POINTER(C.c_uint8)
+_i8p = C.POINTER(C.c_int8)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_sz = C.c_size_t
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs
+    )
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", HERE, "-B", os.path.join(HERE, "libbitnet_oracle.so")])
+    if not os.path.exists(REF_LIB_PATH) or force:
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L: C.CDLL) -> None:
+    gemv_sig = [_u8p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, _sz, C.c_char_p]
+    for name in ("bo_gemv_qk256_scalar", "bo_gemv_qk256_avx2", "bo_gemv_qk256"):
+        getattr(L, name).argtypes = gemv_sig
+        getattr(L, name).restype = C.c_int
+    L.bo_gemv_qk256_avx2_mt.argtypes = [_u8p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, _sz, C.c_int, C.c_char_p]
+    L.bo_gemv_qk256_avx2_mt.restype = C.c_int
+    L.bo_gemv_qk256_f64.argtypes = [_u8p, _f32p, _f64p, _sz, _sz, _sz]
+    L.bo_gemv_qk256_f64.restype = None
+    L.bo_have_avx2.restype = C.c_int
+    L.bo_unpack_qk256_block.argtypes = [_u8p, _u8p]
+    L.bo_code_to_f32.argtypes = [C.c_uint8]
+    L.bo_code_to_f32.restype = C.c_float
+    L.bo_gemv_qk256_row.argtypes = [_u8p, _f32p, _sz]
+    L.bo_gemv_qk256_row.restype = C.c_float
+    L.bo_i2s_qk256_new.argtypes = [_sz, _sz, _sz, C.POINTER(_sz), C.c_char_p]
+    L.bo_i2s_qk256_new.restype = C.c_int
+    L.bo_qk256_dispatch_gemv_scalar.argtypes = [_f32p, _sz, _sz, _u8p, _sz, _f32p, _sz, _f32p, C.c_char_p]
+    L.bo_qk256_dispatch_gemv_scalar.restype = C.c_int
+    L.bo_decode_i2s.argtypes = [C.c_uint8]
+    L.bo_decode_i2s.restype = C.c_int8
+    L.bo_pack_i2s.argtypes = [_i8p]
+    L.bo_pack_i2s.restype = C.c_uint8
+    mm_sig = [_f32p, _sz, _u8p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, _sz, _sz, C.c_char_p]
+    for name in ("bo_i2s_matmul_f32", "bo_i2s_matmul_blocked", "bo_dequantize_and_matmul"):
+        getattr(L, name).argtypes = mm_sig
+        getattr(L, name).restype = C.c_int
+    L.bo_matmul_i2s.argtypes = [_i8p, _sz, _u8p, _sz, _f32p, _sz, _sz, _sz, _sz, C.c_char_p]
+    L.bo_matmul_i2s.restype = C.c_int
+    L.bo_quantize_i2s.argtypes = [_f32p, _sz, _u8p, _sz, _f32p, _sz, C.c_char_p]
+    L.bo_quantize_i2s.restype = C.c_int
+    L.bo_f16_to_f32.argtypes = [C.c_uint16]
+    L.bo_f16_to_f32.restype = C.c_float
+    L.bo_i2s_dequant_block.argtypes = [_f32p, _u8p, _sz, C.c_uint16, C.c_int, C.c_float]
+    L.bo_i2s_expected_bytes.argtypes = [_sz, _sz, _sz]
+    L.bo_i2s_expected_bytes.restype = _sz
+    L.bo_i2s_infer_block_size.argtypes = [_sz, _sz, _sz]
+    L.bo_i2s_infer_block_size.restype = _sz
+    L.bo_i2s_dequantize_to_f32.argtypes = [_u8p, _sz, _sz, _sz, C.c_int, C.c_float, C.c_int, _f32p, C.c_char_p]
+    L.bo_i2s_dequantize_to_f32.restype = C.c_int
+    L.bo_pack_2bit_values.argtypes = [_i8p, _sz, _u8p]
+    L.bo_unpack_2bit_values.argtypes = [_u8p, _sz, _sz, _i8p]
+    L.bo_dequantize_blocks.argtypes = [_i8p, _sz, _f32p, _sz, _f32p]
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def _i8(a):
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    return a, a.ctypes.data_as(_i8p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _check(rc: int, err) -> None:
+    if rc != 0:
+        raise OracleError(err.value.decode() or f"oracle rc={rc}")
+
+
+# ---- QK256 -------------------------------------------------------------
+
+
+def unpack_qk256_block(qs64) -> np.ndarray:
+    q, qp = _u8(qs64)
+    assert q.size == 64
+    out = np.zeros(256, np.uint8)
+    lib().bo_unpack_qk256_block(qp, out.ctypes.data_as(_u8p))
+    return out
+
+
+def code_to_f32(code: int) -> float:
+    return float(lib().bo_code_to_f32(code))
+
+
+def gemv_qk256_row(qs_row, x, cols: int) -> float:
+    q, qp = _u8(qs_row)
+    xa, xp = _f32(x)
+    return float(lib().bo_gemv_qk256_row(qp, xp, cols))
+
+
+def gemv_qk256(qs, x, rows: int, cols: int, row_stride_bytes: int, y_len: int | None = None,
+               impl: str = "dispatch", threads: int = 1) -> np.ndarray:
+    """impl: 'dispatch' (reference behaviour), 'scalar', 'avx2', 'avx2_mt'."""
+    q, qp = _u8(qs)
+    xa, xp = _f32(x)
+    y = np.zeros(rows if y_len is None else y_len, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    L = lib()
+    args = (qp, q.size, xp, xa.size, y.ctypes.data_as(_f32p), y.size, rows, cols, row_stride_bytes)
+    if impl == "avx2_mt":
+        rc = L.bo_gemv_qk256_avx2_mt(*args, threads, err)
+    else:
+        fn = {"dispatch": L.bo_gemv_qk256, "scalar": L.bo_gemv_qk256_scalar, "avx2": L.bo_gemv_qk256_avx2}[impl]
+        rc = fn(*args, err)
+    _check(rc, err)
+    return y
+
+
+def gemv_qk256_f64(qs, x, rows: int, cols: int, row_stride_bytes: int) -> np.ndarray:
+    q, qp = _u8(qs)
+    xa, xp = _f32(x)
+    y = np.zeros(rows, np.float64)
+    lib().bo_gemv_qk256_f64(qp, xp, y.ctypes.data_as(_f64p), rows, cols, row_stride_bytes)
+    return y
+
+
+def have_avx2() -> bool:
+    return bool(lib().bo_have_avx2())
+
+
+def i2s_qk256_new(rows: int, cols: int, qs_len: int) -> int:
+    stride = _sz(0)
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().bo_i2s_qk256_new(rows, cols, qs_len, C.byref(stride), err), err)
+    return stride.value
+
+
+def qk256_dispatch_gemv_scalar(rows, cols, packed, scales, activations) -> np.ndarray:
+    p, pp = _u8(packed)
+    s, sp = _f32(scales)
+    a, ap = _f32(activations)
+    out = np.zeros(rows, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().bo_qk256_dispatch_gemv_scalar(out.ctypes.data_as(_f32p), rows, cols, pp, p.size, sp, s.size, ap, err), err)
+    return out
+
+
+# ---- ternary -----------------------------------------------------------
+
+
+def decode_i2s(bits: int) -> int:
+    return int(lib().bo_decode_i2s(bits))
+
+
+def pack_i2s(vals) -> int:
+    v, vp = _i8(vals)
+    assert v.size == 4
+    return int(lib().bo_pack_i2s(vp))
+
+
+def i2s_matmul(act, w, scales, m, n, k, block_size, impl="f32", out_len=None) -> np.ndarray:
+    a, ap = _f32(act)
+    wq, wp = _u8(w)
+    s, sp = _f32(scales)
+    out = np.zeros(m * n if out_len is None else out_len, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    L = lib()
+    fn = {"f32": L.bo_i2s_matmul_f32, "blocked": L.bo_i2s_matmul_blocked, "dequant": L.bo_dequantize_and_matmul}[impl]
+    _check(fn(ap, a.size, wp, wq.size, sp, s.size, out.ctypes.data_as(_f32p), out.size, m, n, k, block_size, err), err)
+    return out
+
+
+# ---- provider ----------------------------------------------------------
+
+
+def matmul_i2s(a, b, m, n, k, c_len=None) -> np.ndarray:
+    aa, ap = _i8(a)
+    bb, bp = _u8(b)
+    c = np.zeros(m * n if c_len is None else c_len, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().bo_matmul_i2s(ap, aa.size, bp, bb.size, c.ctypes.data_as(_f32p), c.size, m, n, k, err), err)
+    return c
+
+
+def quantize_i2s(x, out_len=None, scales_len=None):
+    xa, xp = _f32(x)
+    out = np.zeros(xa.size // 4 if out_len is None else out_len, np.uint8)
+    scales = np.zeros((xa.size + 31) // 32 if scales_len is None else scales_len, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().bo_quantize_i2s(xp, xa.size, out.ctypes.data_as(_u8p), out.size, scales.ctypes.data_as(_f32p), scales.size, err), err)
+    return out, scales
+
+
+# ---- block dequant -----------------------------------------------------
+
+
+def f16_to_f32(bits: int) -> float:
+    return float(lib().bo_f16_to_f32(bits))
+
+
+def i2s_dequant_block(qbits, n, scale_bits, inv=False, k=1.0) -> np.ndarray:
+    q, qp = _u8(qbits)
+    dst = np.zeros(n, np.float32)
+    lib().bo_i2s_dequant_block(dst.ctypes.data_as(_f32p), qp, n, scale_bits, int(inv), k)
+    return dst
+
+
+def i2s_expected_bytes(rows, cols, block) -> int:
+    return int(lib().bo_i2s_expected_bytes(rows, cols, block))
+
+
+def i2s_infer_block_size(nbytes, rows, cols):
+    b = int(lib().bo_i2s_infer_block_size(nbytes, rows, cols))
+    return b or None
+
+
+def i2s_dequantize_to_f32(data, rows, cols, inv=False, k=1.0, transposed=False) -> np.ndarray:
+    d, dp = _u8(data)
+    out = np.zeros(rows * cols, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().bo_i2s_dequantize_to_f32(dp, d.size, rows, cols, int(inv), k, int(transposed), out.ctypes.data_as(_f32p), err), err)
+    return out
+
+
+# ---- Q/utils.rs --------------------------------------------------------
+
+
+def pack_2bit_values(values) -> np.ndarray:
+    v, vp = _i8(values)
+    out = np.zeros((v.size + 3) // 4, np.uint8)
+    lib().bo_pack_2bit_values(vp, v.size, out.ctypes.data_as(_u8p))
+    return out
+
+
+def unpack_2bit_values(packed, output_len) -> np.ndarray:
+    p, pp = _u8(packed)
+    out = np.zeros(output_len, np.int8)
+    lib().bo_unpack_2bit_values(pp, p.size, output_len, out.ctypes.data_as(_i8p))
+    return out
+
+
+def dequantize_blocks(q, scales, block_size) -> np.ndarray:
+    qa, qp = _i8(q)
+    s, sp = _f32(scales)
+    out = np.zeros(qa.size, np.float32)
+    lib().bo_dequantize_blocks(qp, qa.size, sp, block_size, out.ctypes.data_as(_f32p))
+    return out
+
+
+# ---- oracle/_ref: the reference's own vendored C, compiled where it lies ----
+
+
+class _BlockIq2s(C.Structure):
+    _pack_ = 1
+    _fields_ = [("d", C.c_uint16), ("qs", C.c_uint8 * 64), ("qh", C.c_uint8 * 8), ("scales", C.c_uint8 * 8)]
+
+
+def ref_available() -> bool:
+    return os.path.exists(REF_LIB_PATH)
+
+
+def ref_dequantize_row_iq2_s(d_bits: int, qs64) -> np.ndarray:
+    """Run the reference's dequantize_row_iq2_s
+    (crates/bitnet-ggml-ffi/csrc/ggml/src/ggml-quants.c:59-72) on one block."""
+    R = C.CDLL(REF_LIB_PATH)
+    R.dequantize_row_iq2_s.argtypes = [C.c_void_p, _f32p, C.c_int64]
+    blk = _BlockIq2s()
+    assert C.sizeof(blk) == 82
+    blk.d = d_bits
+    q = np.ascontiguousarray(qs64, dtype=np.uint8)
+    for i in range(64):
+        blk.qs[i] = int(q[i])
+    y = np.zeros(256, np.float32)
+    R.dequantize_row_iq2_s(C.byref(blk), y.ctypes.data_as(_f32p), 256)
+    return y
