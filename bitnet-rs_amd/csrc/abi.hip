@@ -1,0 +1,481 @@
+// abi.hip -- the extern "C" surface declared in include/bitnet_hip.h.
+//
+// Argument validation mirrors the reference function each symbol replaces (cited in
+// the header); kernels live in kernels_*.hip.  No CPU fallback exists here: every
+// compute path needs a HIP device.
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+thread_local std::string g_last_error;
+
+namespace {
+
+std::mutex g_mu;
+bool g_inited = false;
+int g_device = 0;
+int g_kernel = BITNET_HIP_KERNEL_AUTO;
+uint64_t g_next_handle = 1;
+std::unordered_map<uint64_t, Weights *> g_weights;
+
+void free_weights(Weights *w) {
+    if (!w) return;
+    if (w->codes) (void)hipFree(w->codes);
+    if (w->scales) (void)hipFree(w->scales);
+    if (w->tiles) (void)hipFree(w->tiles);
+    delete w;
+}
+
+Weights *lookup(bitnet_hip_weights_t h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_weights.find(h);
+    return it == g_weights.end() ? nullptr : it->second;
+}
+
+int ensure_init() {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_inited) return BITNET_HIP_OK;
+    }
+    return bitnet_hip_init(-1);
+}
+
+int register_weights(Weights *w, bitnet_hip_weights_t *out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint64_t h = g_next_handle++;
+    g_weights[h] = w;
+    *out = h;
+    return BITNET_HIP_OK;
+}
+
+// RAII device scratch for the host-pointer drop-ins.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T>
+    T *as() {
+        return static_cast<T *>(p);
+    }
+};
+
+int run_gemv(const Weights &w, const float *x_dev, float *y_dev, size_t m, hipStream_t stream) {
+    int kernel = g_kernel;
+    if (kernel == BITNET_HIP_KERNEL_AUTO || kernel == BITNET_HIP_KERNEL_MFMA)
+        kernel = valu_supported(w) ? BITNET_HIP_KERNEL_VALU : BITNET_HIP_KERNEL_EXACT;
+    if (kernel == BITNET_HIP_KERNEL_VALU && !valu_supported(w)) kernel = BITNET_HIP_KERNEL_EXACT;
+    hipError_t e = kernel == BITNET_HIP_KERNEL_VALU ? launch_gemv_valu(w, x_dev, y_dev, m, stream)
+                                                    : launch_gemv_exact(w, x_dev, y_dev, m, stream);
+    if (e != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+}
+
+}  // namespace
+}  // namespace bitnet_hip
+
+using namespace bitnet_hip;
+
+#define BH_GUARD_BEGIN try {
+#define BH_GUARD_END                                                                     \
+    }                                                                                    \
+    catch (const std::exception &e) {                                                    \
+        return set_error(BITNET_HIP_ERR_EXECUTION, "%s", e.what());                      \
+    }                                                                                    \
+    catch (...) {                                                                        \
+        return set_error(BITNET_HIP_ERR_EXECUTION, "unknown C++ exception");             \
+    }
+
+extern "C" {
+
+int bitnet_hip_init(int device) {
+    BH_GUARD_BEGIN
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(BITNET_HIP_ERR_GPU, "no HIP device available (hipGetDeviceCount: %s)",
+                         hipGetErrorString(e));
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d visible)", device,
+                         count);
+    BH_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED,
+                         "device %d is %s; this library carries gfx950 (MI355X) code objects only",
+                         device, prop.gcnArchName);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_device = device;
+    g_inited = true;
+    g_last_error.clear();
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+void bitnet_hip_cleanup(void) {
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto &kv : g_weights) free_weights(kv.second);
+        g_weights.clear();
+        g_inited = false;
+        g_last_error.clear();
+    } catch (...) {
+    }
+}
+
+int bitnet_hip_is_available(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? 1 : 0;
+}
+
+int bitnet_hip_device_count(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+const char *bitnet_hip_get_last_error(void) {
+    return g_last_error.empty() ? nullptr : g_last_error.c_str();
+}
+
+int bitnet_hip_get_device_info(int device, bitnet_hip_device_info *out) {
+    BH_GUARD_BEGIN
+    if (!out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to get_device_info");
+    hipDeviceProp_t prop;
+    BH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    memset(out, 0, sizeof(*out));
+    out->device_id = device;
+    strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    strncpy(out->gcn_arch, prop.gcnArchName, sizeof(out->gcn_arch) - 1);
+    out->total_memory = prop.totalGlobalMem;
+    out->compute_unit_count = prop.multiProcessorCount;
+    out->max_wavefront_size = prop.warpSize;
+    out->max_shared_memory_per_workgroup = prop.sharedMemPerBlock;
+    out->supports_fp16 = 1;
+    out->supports_bf16 = 1;
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_set_kernel(int kernel) {
+    if (kernel < BITNET_HIP_KERNEL_AUTO || kernel > BITNET_HIP_KERNEL_MFMA)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+    g_kernel = kernel;
+    return BITNET_HIP_OK;
+}
+
+int bitnet_hip_get_kernel(void) { return g_kernel; }
+
+/* ---------------------------------------------------------------- handles */
+
+int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_t rows, size_t cols,
+                                    size_t row_stride_bytes, bitnet_hip_weights_t *out) {
+    BH_GUARD_BEGIN
+    if (!qs_data || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_qk256");
+    if (rows == 0 || cols == 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2SQk256NoScale: rows and cols must be > 0");
+    const size_t stride = div_ceil(cols, 256) * 64;
+    if (row_stride_bytes != stride)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "I2S_QK256: row bytes mismatch: got %zu, expected %zu for %zu cols",
+                         row_stride_bytes, stride, cols);
+    const size_t expected = rows * stride;
+    const size_t diff = qs_len > expected ? qs_len - expected : expected - qs_len;
+    if (diff > 128)  // Q/i2s_qk256.rs:91-103
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "I2SQk256NoScale: data size mismatch: got %zu bytes, expected %zu for %zux%zu "
+                         "matrix. Check tensor orientation: QK256 requires [out_dim, in_dim] layout.",
+                         qs_len, expected, rows, cols);
+    if (qs_len < expected)  // gemv_qk256 would refuse it (Q/i2s_qk256.rs:308-311)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2S_QK256: data too short: %zu < %zu", qs_len,
+                         expected);
+    int rc = ensure_init();
+    if (rc) return rc;
+    Weights *w = new Weights();
+    w->rows = rows;
+    w->cols = cols;
+    w->row_stride_bytes = stride;
+    w->lut = LUT_QK256;
+    w->algorithmic_bytes = expected;
+    w->device = g_device;
+    if (hipMalloc((void **)&w->codes, expected) != hipSuccess) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc(%zu) failed for QK256 codes", expected);
+    }
+    if (hipMemcpy(w->codes, qs_data, expected, hipMemcpyHostToDevice) != hipSuccess) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy H2D failed for QK256 codes");
+    }
+    return register_weights(w, out);
+    BH_GUARD_END
+}
+
+int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                  size_t scales_len, size_t n, size_t k, size_t block_size,
+                                  bitnet_hip_weights_t *out) {
+    BH_GUARD_BEGIN
+    if (!weights_packed || !scales || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_i2s");
+    if (block_size == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "block_size must be > 0");
+    if (n == 0 || k == 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: n=%zu, k=%zu", n, k);
+    const size_t packed_k = div_ceil(k, 4), nblk = div_ceil(k, block_size);
+    if (w_len < packed_k * n)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_packed too small: expected %zu, got %zu",
+                         packed_k * n, w_len);
+    if (scales_len < n * nblk)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "scales too small: expected %zu, got %zu",
+                         n * nblk, scales_len);
+    int rc = ensure_init();
+    if (rc) return rc;
+    Weights *w = new Weights();
+    w->rows = n;
+    w->cols = k;
+    w->row_stride_bytes = packed_k;
+    w->block_size = block_size;
+    w->nblk = nblk;
+    w->lut = LUT_TERNARY;
+    w->algorithmic_bytes = packed_k * n + 4 * n * nblk;
+    w->device = g_device;
+    if (hipMalloc((void **)&w->codes, packed_k * n + 16) != hipSuccess ||
+        hipMalloc((void **)&w->scales, 4 * n * nblk) != hipSuccess) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed for I2_S weights");
+    }
+    if (hipMemcpy(w->codes, weights_packed, packed_k * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(w->scales, scales, 4 * n * nblk, hipMemcpyHostToDevice) != hipSuccess) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy H2D failed for I2_S weights");
+    }
+    return register_weights(w, out);
+    BH_GUARD_END
+}
+
+int bitnet_hip_weights_free(bitnet_hip_weights_t h) {
+    BH_GUARD_BEGIN
+    Weights *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_weights.find(h);
+        if (it == g_weights.end())
+            return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu",
+                             (unsigned long long)h);
+        w = it->second;
+        g_weights.erase(it);
+    }
+    free_weights(w);
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_weights_info(bitnet_hip_weights_t h, size_t *rows, size_t *cols, size_t *algorithmic_bytes) {
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (rows) *rows = w->rows;
+    if (cols) *cols = w->cols;
+    if (algorithmic_bytes) *algorithmic_bytes = w->algorithmic_bytes;
+    return BITNET_HIP_OK;
+}
+
+int bitnet_hip_gemv_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, void *stream) {
+    return bitnet_hip_matmul_dev(h, x_dev, y_dev, 1, stream);
+}
+
+int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m, void *stream) {
+    BH_GUARD_BEGIN
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_dev");
+    if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    return run_gemv(*w, x_dev, y_dev, m, (hipStream_t)stream);
+    BH_GUARD_END
+}
+
+/* ------------------------------------------------- host-pointer drop-ins */
+
+int bitnet_hip_gemv_qk256(const uint8_t *qs_data, size_t qs_len, const float *x, size_t x_len, float *y_out,
+                          size_t y_len, size_t rows, size_t cols, size_t row_stride_bytes) {
+    BH_GUARD_BEGIN
+    if (!qs_data || !x || !y_out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_qk256");
+    // Q/i2s_qk256.rs:301-311, same order, same wording
+    if (y_len != rows)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2S_QK256: y_out length %zu != rows %zu", y_len, rows);
+    if (x_len < cols)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2S_QK256: x length %zu < cols %zu", x_len, cols);
+    const size_t expected_total = rows * row_stride_bytes;
+    if (qs_len < expected_total)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2S_QK256: data too short: %zu < %zu", qs_len, expected_total);
+    if (rows == 0) return BITNET_HIP_OK;  // nothing to write; the reference's loop is empty too
+    if (cols == 0) {
+        memset(y_out, 0, rows * sizeof(float));  // empty dot product
+        return BITNET_HIP_OK;
+    }
+    if (row_stride_bytes != div_ceil(cols, 256) * 64)  // debug_assert :200-207
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "I2S_QK256: row bytes mismatch: got %zu, expected %zu for %zu cols", row_stride_bytes,
+                         div_ceil(cols, 256) * 64, cols);
+    bitnet_hip_weights_t h = 0;
+    int rc = bitnet_hip_weights_upload_qk256(qs_data, expected_total, rows, cols, row_stride_bytes, &h);
+    if (rc) return rc;
+    DevBuf xd, yd;
+    rc = BITNET_HIP_OK;
+    if (xd.alloc(cols * 4) != hipSuccess || yd.alloc(rows * 4) != hipSuccess ||
+        hipMemcpy(xd.p, x, cols * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_error(BITNET_HIP_ERR_GPU, "device staging failed in gemv_qk256");
+    if (!rc) rc = bitnet_hip_gemv_dev(h, xd.as<float>(), yd.as<float>(), nullptr);
+    if (!rc && hipMemcpy(y_out, yd.p, rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = set_error(BITNET_HIP_ERR_GPU, "hipMemcpy D2H failed in gemv_qk256");
+    std::string keep = g_last_error;
+    bitnet_hip_weights_free(h);
+    if (rc) g_last_error = keep;
+    return rc;
+    BH_GUARD_END
+}
+
+int bitnet_hip_i2s_matmul_f32(const float *act, size_t act_len, const uint8_t *wp, size_t w_len,
+                              const float *scales, size_t scales_len, float *out, size_t out_len, size_t m,
+                              size_t n, size_t k, size_t block_size) {
+    BH_GUARD_BEGIN
+    if (!act || !wp || !scales || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to i2s_matmul_f32");
+    // K/cpu/quantized_matmul.rs:204-256
+    if (block_size == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "block_size must be > 0");
+    if (m == 0 || n == 0 || k == 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=%zu, n=%zu, k=%zu", m, n, k);
+    const size_t packed_k = div_ceil(k, 4), nblk = div_ceil(k, block_size);
+    if (act_len < m * k)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "activations too small: expected %zu, got %zu", m * k, act_len);
+    if (w_len < packed_k * n)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_packed too small: expected %zu, got %zu", packed_k * n, w_len);
+    if (scales_len < n * nblk)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "scales too small: expected %zu, got %zu", n * nblk, scales_len);
+    if (out_len < m * n)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "output too small: expected %zu, got %zu", m * n, out_len);
+    bitnet_hip_weights_t h = 0;
+    int rc = bitnet_hip_weights_upload_i2s(wp, w_len, scales, scales_len, n, k, block_size, &h);
+    if (rc) return rc;
+    DevBuf xd, yd;
+    if (xd.alloc(m * k * 4) != hipSuccess || yd.alloc(m * n * 4) != hipSuccess ||
+        hipMemcpy(xd.p, act, m * k * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_error(BITNET_HIP_ERR_GPU, "device staging failed in i2s_matmul_f32");
+    if (!rc) rc = bitnet_hip_matmul_dev(h, xd.as<float>(), yd.as<float>(), m, nullptr);
+    if (!rc) {
+        memset(out, 0, out_len * sizeof(float));  // out.fill(0.0) :72
+        if (hipMemcpy(out, yd.p, m * n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = set_error(BITNET_HIP_ERR_GPU, "hipMemcpy D2H failed in i2s_matmul_f32");
+    }
+    std::string keep = g_last_error;
+    bitnet_hip_weights_free(h);
+    if (rc) g_last_error = keep;
+    return rc;
+    BH_GUARD_END
+}
+
+int bitnet_hip_qk256_gemv(const uint8_t *weights, size_t w_len, const float *scales, size_t scales_len,
+                          const float *input, size_t in_len, float *output, size_t out_len, size_t m, size_t n,
+                          size_t k) {
+    if (k % 256 != 0 || k == 0) {  // K/cuda/qk256_gemv.rs:60-68
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "QK256 GEMV inner dimension k=%zu must be a positive multiple of 256", k);
+    }
+    return bitnet_hip_i2s_matmul_f32(input, in_len, weights, w_len, scales, scales_len, output, out_len, m, n, k, 256);
+}
+
+int bitnet_hip_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_t b_len, float *c, size_t c_len,
+                          size_t m, size_t n, size_t k) {
+    BH_GUARD_BEGIN
+    if (!a || !b || !c) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_i2s");
+    // K/cpu/fallback.rs:49-63
+    if (a_len != m * k)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix A dimension mismatch: expected %zu, got %zu", m * k, a_len);
+    if (b_len != k * n)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix B dimension mismatch: expected %zu, got %zu", k * n, b_len);
+    if (c_len != m * n)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix C dimension mismatch: expected %zu, got %zu", m * n, c_len);
+    if (m * n == 0) return BITNET_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf ad, bd, cd;
+    if (ad.alloc(a_len) != hipSuccess || bd.alloc(b_len) != hipSuccess || cd.alloc(c_len * 4) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in matmul_i2s");
+    BH_HIP_TRY(hipMemcpy(ad.p, a, a_len, hipMemcpyHostToDevice));
+    BH_HIP_TRY(hipMemcpy(bd.p, b, b_len, hipMemcpyHostToDevice));
+    BH_HIP_TRY(launch_matmul_i2s_u8(ad.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
+    BH_HIP_TRY(hipMemcpy(c, cd.p, c_len * 4, hipMemcpyDeviceToHost));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_quantize(const float *input, size_t input_len, uint8_t *output, size_t output_len, float *scales,
+                        size_t scales_len, int qtype) {
+    BH_GUARD_BEGIN
+    if (!input || !output || !scales) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to quantize");
+    if (qtype < 0 || qtype > 2) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Invalid quantization type");
+    if (qtype != BITNET_HIP_QTYPE_I2S)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "quantize: only I2_S is implemented on the ROCm hot path (qtype=%d)", qtype);
+    // K/cpu/fallback.rs:104-124
+    const size_t num_blocks = div_ceil(input_len, 32);
+    if (output_len < input_len / 4)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Output buffer too small for I2_S: expected %zu, got %zu", input_len / 4, output_len);
+    if (scales_len < num_blocks)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Scales buffer too small: expected %zu, got %zu", num_blocks, scales_len);
+    if (input_len == 0) return BITNET_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf id, od, sd;
+    if (id.alloc(input_len * 4) != hipSuccess || od.alloc(output_len) != hipSuccess || sd.alloc(num_blocks * 4) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in quantize");
+    BH_HIP_TRY(hipMemcpy(id.p, input, input_len * 4, hipMemcpyHostToDevice));
+    BH_HIP_TRY(hipMemcpy(od.p, output, output_len, hipMemcpyHostToDevice));  // OR-pack semantics
+    BH_HIP_TRY(launch_quantize_i2s(id.as<float>(), input_len, od.as<uint8_t>(), output_len, sd.as<float>(), nullptr));
+    BH_HIP_TRY(hipMemcpy(output, od.p, output_len, hipMemcpyDeviceToHost));
+    BH_HIP_TRY(hipMemcpy(scales, sd.p, num_blocks * 4, hipMemcpyDeviceToHost));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_dequant_i2s(const uint8_t *bytes, size_t bytes_len, size_t rows, size_t cols, int inv_scale, float k,
+                           int transposed, float *out, size_t out_len) {
+    BH_GUARD_BEGIN
+    if (!bytes || !out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to dequant_i2s");
+    if (rows == 0 || cols == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2_S: empty tensor dims");
+    if (out_len < rows * cols)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2_S: output bounds exceeded: %zu > %zu", rows * cols, out_len);
+    // M/quant/i2s.rs:205-214 (non-transposed tries 256 first, which the candidate
+    // order {256,128,64,32} already does)
+    size_t block = 0;
+    for (size_t b : {size_t(256), size_t(128), size_t(64), size_t(32)}) {
+        if (rows * div_ceil(cols, b) * (b / 4 + 2) == bytes_len) {
+            block = b;
+            break;
+        }
+    }
+    if (!block)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "I2_S: byte length mismatch (got %zu for %zux%zu): no block size in {256,128,64,32} fits",
+                         bytes_len, rows, cols);
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf bd, od;
+    if (bd.alloc(bytes_len) != hipSuccess || od.alloc(rows * cols * 4) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in dequant_i2s");
+    BH_HIP_TRY(hipMemcpy(bd.p, bytes, bytes_len, hipMemcpyHostToDevice));
+    BH_HIP_TRY(launch_dequant_i2s(bd.as<uint8_t>(), rows, cols, block, inv_scale, k, transposed, od.as<float>(), nullptr));
+    BH_HIP_TRY(hipMemcpy(out, od.p, rows * cols * 4, hipMemcpyDeviceToHost));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+}  // extern "C"

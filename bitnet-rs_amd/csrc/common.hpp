@@ -1,0 +1,82 @@
+// common.hpp -- shared host-side plumbing for libbitnet_hip.so (gfx950 only).
+//
+// Error convention follows the reference's C bridge (K/ffi/cpp_bridge.cpp:19-27):
+// thread-local last-error string, int return codes, nothing thrown across the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "bitnet_hip.h"
+
+namespace bitnet_hip {
+
+extern thread_local std::string g_last_error;
+
+inline int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define BH_HIP_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::bitnet_hip::set_error(BITNET_HIP_ERR_GPU, "HIP error %d (%s) at %s:%d: %s", \
+                                           (int)_e, hipGetErrorName(_e), __FILE__, __LINE__,   \
+                                           #expr);                                             \
+    } while (0)
+
+inline size_t div_ceil(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// Code -> value maps used by the reference (SURVEY.md 8a "code-map summary"),
+// packed as four int8 in one u32 (byte c = value of code c).
+constexpr uint32_t pack_lut(int v0, int v1, int v2, int v3) {
+    return (uint32_t)(uint8_t)(int8_t)v0 | ((uint32_t)(uint8_t)(int8_t)v1 << 8) |
+           ((uint32_t)(uint8_t)(int8_t)v2 << 16) | ((uint32_t)(uint8_t)(int8_t)v3 << 24);
+}
+constexpr uint32_t LUT_QK256 = pack_lut(-2, -1, 1, 2);    // Q/i2s_qk256.rs:139-146
+constexpr uint32_t LUT_TERNARY = pack_lut(0, 1, 0, -1);   // K/cpu/quantized_matmul.rs:19-27
+
+// Device-resident weight matrix behind a bitnet_hip_weights_t handle.
+struct Weights {
+    size_t rows = 0;              // output features (n)
+    size_t cols = 0;              // input features (k)
+    size_t row_stride_bytes = 0;  // code bytes per row in `codes`
+    size_t block_size = 0;        // scale block along k (0 = no scales)
+    size_t nblk = 0;              // scale blocks per row
+    uint32_t lut = 0;             // pack_lut(...)
+    uint8_t *codes = nullptr;     // [rows, row_stride_bytes], reference layout
+    float *scales = nullptr;      // [rows, nblk] f32 or null
+    size_t algorithmic_bytes = 0; // code bytes + scale bytes
+    int device = 0;
+    // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
+    // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
+    uint8_t *tiles = nullptr;
+    size_t n_row_tiles = 0, n_kblocks = 0;
+};
+
+// ---- kernel launchers (kernels_*.hip) -------------------------------------
+// All launchers are asynchronous on `stream` and return hipGetLastError().
+
+hipError_t launch_gemv_exact(const Weights &w, const float *x, float *y, size_t m, hipStream_t stream);
+hipError_t launch_gemv_valu(const Weights &w, const float *x, float *y, size_t m, hipStream_t stream);
+bool valu_supported(const Weights &w);
+hipError_t launch_matmul_i2s_u8(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n,
+                                size_t k, hipStream_t stream);
+hipError_t launch_quantize_i2s(const float *in, size_t n, uint8_t *out, size_t out_len, float *scales,
+                               hipStream_t stream);
+hipError_t launch_dequant_i2s(const uint8_t *bytes, size_t rows, size_t cols, size_t block, int inv,
+                              float k, int transposed, float *out, hipStream_t stream);
+
+}  // namespace bitnet_hip

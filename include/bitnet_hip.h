@@ -1,0 +1,183 @@
+/*
+ * bitnet_hip.h -- C ABI of libbitnet_hip.so: the MI355X (gfx950) drop-in for the
+ * I2_S / QK256 hot path of EffortlessMetrics/BitNet-rs.
+ *
+ * This is the boundary the reference's `bitnet-kernels` ROCm provider would bind
+ * (`extern "C"`, plain pointers and sizes).  Each entry point names the reference
+ * interface it replaces (path:line under the reference checkout).  Prefixes:
+ *   K/ = crates/bitnet-kernels/src/   Q/ = crates/bitnet-quantization/src/
+ *   M/ = crates/bitnet-models/src/    T  = crates/bitnet-transformer/src/lib.rs
+ *
+ * Conventions (identical to the reference's existing C bridge, K/ffi/bridge.rs:17-39
+ * and K/ffi/cpp_bridge.cpp:19-27,76-86,112-118):
+ *   - every fallible call returns int: 0 = success, non-zero = error;
+ *   - the error text is kept in a thread-local string, valid until the next call
+ *     on the same thread, read with bitnet_hip_get_last_error();
+ *   - the caller owns every buffer; nothing is retained past return (handles own
+ *     their device copies); outputs are fully overwritten;
+ *   - no exception crosses the boundary; entry points are re-entrant.
+ *
+ * Two families:
+ *   1. host-pointer drop-ins: argument lists mirror the Rust slices 1:1
+ *      (pointer + length), synchronous and self-contained (H2D, launch, D2H),
+ *      like the reference GPU provider does per call (K/gpu/cuda.rs:287-336);
+ *   2. device-resident API: upload weights once -> opaque handle; activations
+ *      and outputs are device pointers; optional hipStream_t (void*).  This is the
+ *      measured path.
+ *
+ * There is NO CPU fallback behind any symbol: without a HIP device every compute
+ * entry point fails with BITNET_HIP_ERR_GPU.
+ */
+#ifndef BITNET_HIP_H
+#define BITNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Return codes.  Mapping to crates/bitnet-common/src/error.rs:80-97 KernelError:
+ *   INVALID_ARGUMENT -> InvalidArguments, GPU -> GpuError,
+ *   UNSUPPORTED -> UnsupportedHardware, EXECUTION -> ExecutionFailed. */
+#define BITNET_HIP_OK 0
+#define BITNET_HIP_ERR_INVALID_ARGUMENT (-1) /* same value cpp_bridge.cpp returns for null/size errors */
+#define BITNET_HIP_ERR_GPU (-2)
+#define BITNET_HIP_ERR_UNSUPPORTED (-3)
+#define BITNET_HIP_ERR_EXECUTION (-4)
+
+/* QuantizationType ints, K/ffi.rs:40-44 */
+#define BITNET_HIP_QTYPE_I2S 0
+#define BITNET_HIP_QTYPE_TL1 1
+#define BITNET_HIP_QTYPE_TL2 2
+
+/* ------------------------------------------------------------------------- */
+/* lifecycle  (K/ffi/bridge.rs:18-20,38: bitnet_cpp_init/cleanup/is_available/ */
+/*             get_last_error;  K/rocm/mod.rs:125-137: is_rocm_available,      */
+/*             rocm_device_count)                                              */
+/* ------------------------------------------------------------------------- */
+
+/* Idempotent.  Selects `device` for the calling thread and creates the library's
+ * internal workspace.  device < 0 means "current device". */
+int bitnet_hip_init(int device);
+void bitnet_hip_cleanup(void);
+/* Non-zero iff at least one HIP device is visible.  The BITNET_ENABLE_ROCM=1
+ * opt-in (K/rocm/mod.rs:76-81) stays on the host side of the boundary. */
+int bitnet_hip_is_available(void);
+int bitnet_hip_device_count(void);
+/* NULL when no error is recorded on this thread (cpp_bridge.cpp:281-283). */
+const char *bitnet_hip_get_last_error(void);
+
+/* K/rocm/mod.rs:33-53 RocmDeviceInfo */
+typedef struct bitnet_hip_device_info {
+    int32_t device_id;
+    char name[128];
+    char gcn_arch[64];
+    uint64_t total_memory;
+    int32_t compute_unit_count;
+    int32_t max_wavefront_size;
+    uint64_t max_shared_memory_per_workgroup;
+    int32_t supports_fp16;
+    int32_t supports_bf16;
+} bitnet_hip_device_info;
+int bitnet_hip_get_device_info(int device, bitnet_hip_device_info *out);
+
+/* ------------------------------------------------------------------------- */
+/* 1. host-pointer drop-ins                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* gemv_qk256(qs_data:&[u8], x:&[f32], y_out:&mut [f32], rows, cols, row_stride_bytes)
+ * Q/i2s_qk256.rs:346-353 (live call sites T:684, T:924,
+ * crates/bitnet-inference/src/layers/quantized_linear.rs:572).
+ * y[r] = sum_j LUT[code(r,j)] * x[j], LUT {-2,-1,+1,+2}, LSB-first 2-bit codes,
+ * tail cols%256 ignored.  Error text keeps the substrings the reference's tests
+ * assert ("y_out length", "x length", "too short"; Q/i2s_qk256.rs:701-739). */
+int bitnet_hip_gemv_qk256(const uint8_t *qs_data, size_t qs_len, const float *x, size_t x_len,
+                          float *y_out, size_t y_len, size_t rows, size_t cols,
+                          size_t row_stride_bytes);
+
+/* i2s_matmul_f32(activations, weights_packed, scales, out, m, n, k, block_size)
+ * K/cpu/quantized_matmul.rs:57-66 == i2s_matmul_forward(act,w,scales,out,&I2sMatmulConfig)
+ * K/cuda/quantized_matmul.rs:309-326.
+ * out[r,c] = sum_blk sum_{i in blk} act[r,i] * (t(code(c,i)) * scales[c*nb+blk]),
+ * t: 0->0, 1->+1, 3->-1, 2->0; weights [n, ceil(k/4)] bytes; scales f32 [n, ceil(k/bs)]. */
+int bitnet_hip_i2s_matmul_f32(const float *activations, size_t act_len,
+                              const uint8_t *weights_packed, size_t w_len, const float *scales,
+                              size_t scales_len, float *out, size_t out_len, size_t m, size_t n,
+                              size_t k, size_t block_size);
+
+/* qk256_gemv_hip(weights, scales, input, output, m, n, k, &Qk256GemvConfig)
+ * K/rocm/qk256_gemv.rs:52-65 -- the stub this library fills.  Semantics are those
+ * the CUDA twin documents (K/cuda/qk256_gemv.rs:1-16, K/cuda/quantized_matmul.rs:7-9):
+ * ternary codes, one f32 scale per 256-element block: input [m,k], weights
+ * [n, k/4], scales [n, k/256], output [m,n].  == i2s_matmul_f32 with block 256. */
+int bitnet_hip_qk256_gemv(const uint8_t *weights, size_t w_len, const float *scales,
+                          size_t scales_len, const float *input, size_t in_len, float *output,
+                          size_t out_len, size_t m, size_t n, size_t k);
+
+/* KernelProvider::matmul_i2s(a:&[i8], b:&[u8], c:&mut [f32], m, n, k)
+ * K/lib.rs:44-52; arithmetic of K/cpu/fallback.rs:39-83 (C = A_i8 . B_u8, B is
+ * UNPACKED u8 row-major [k,n], no scale); FFI twin bitnet_cpp_matmul_i2s
+ * K/ffi/bridge.rs:21-28. */
+int bitnet_hip_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_t b_len, float *c,
+                          size_t c_len, size_t m, size_t n, size_t k);
+
+/* KernelProvider::quantize(input, output, scales, qtype)  K/lib.rs:53-58;
+ * I2S arithmetic of K/cpu/fallback.rs:102-159 (block 32, scale = absmax/1.5,
+ * >0.5 -> 1, <-0.5 -> 3, else 0, OR-packed LSB-first into `output`, which the
+ * caller zeroes); FFI twin bitnet_cpp_quantize K/ffi/bridge.rs:29-37.
+ * Only qtype I2S is on the hot path; TL1/TL2 return BITNET_HIP_ERR_UNSUPPORTED. */
+int bitnet_hip_quantize(const float *input, size_t input_len, uint8_t *output, size_t output_len,
+                        float *scales, size_t scales_len, int qtype);
+
+/* dequantize_to_f32[_transposed][_with_cfg](bytes, shape, cfg)
+ * M/quant/i2s.rs:237, :448, :591, :774 -- blocks of ceil(bs/4) code bytes + 2 B LE
+ * f16 scale, value = clamp(|f16|[^-1]*k, 1e-3, 1e3) * {-2,-1,+1,+2}[code]; block size
+ * inferred from the byte count among {256,128,64,32}.  Unlike the reference's
+ * lenient partial-data path, a byte count matching no block size is an error. */
+int bitnet_hip_dequant_i2s(const uint8_t *bytes, size_t bytes_len, size_t rows, size_t cols,
+                           int inv_scale, float k, int transposed, float *out, size_t out_len);
+
+/* ------------------------------------------------------------------------- */
+/* 2. device-resident API                                                      */
+/* ------------------------------------------------------------------------- */
+
+typedef uint64_t bitnet_hip_weights_t; /* opaque; 0 is never a valid handle */
+
+/* Kernel selection for the device GEMV/matmul (bitnet_hip_set_kernel). */
+#define BITNET_HIP_KERNEL_AUTO 0
+#define BITNET_HIP_KERNEL_EXACT 1 /* one thread per output, reference summation order: bit-exact */
+#define BITNET_HIP_KERNEL_VALU 2  /* wave-per-row, f32 FMA, shuffle reduction */
+#define BITNET_HIP_KERNEL_MFMA 3  /* i8 MFMA on exact fixed-point activation digits */
+int bitnet_hip_set_kernel(int kernel);
+int bitnet_hip_get_kernel(void);
+
+/* I2SQk256NoScale {rows, cols, row_stride_bytes, qs}  Q/i2s_qk256.rs:66-106:
+ * accepts qs_len within +-128 B of rows*row_stride (the reference's alignment
+ * slack); map {-2,-1,+1,+2}, no scale. */
+int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_t rows,
+                                    size_t cols, size_t row_stride_bytes,
+                                    bitnet_hip_weights_t *out);
+/* Ternary weights of K/cpu/quantized_matmul.rs:47-56: [n, ceil(k/4)] code bytes +
+ * f32 scales [n, ceil(k/block_size)], block_size 32 (BitNet32-F16) or 256. */
+int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                  size_t scales_len, size_t n, size_t k, size_t block_size,
+                                  bitnet_hip_weights_t *out);
+int bitnet_hip_weights_free(bitnet_hip_weights_t w);
+/* rows (n), cols (k), algorithmic bytes one GEMV reads from this handle
+ * (code bytes + scale bytes). */
+int bitnet_hip_weights_info(bitnet_hip_weights_t w, size_t *rows, size_t *cols,
+                            size_t *algorithmic_bytes);
+
+/* y_dev[rows] = W . x_dev[cols]   (one activation row: batch-1 decode) */
+int bitnet_hip_gemv_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, void *stream);
+/* Y_dev[m, rows] = X_dev[m, cols] . W^T   (forward_qk256's per-row loop T:683-691,
+ * batched; row-major, leading dimensions cols / rows) */
+int bitnet_hip_matmul_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BITNET_HIP_H */

@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, validates arguments like the reference does, and fails loudly (no
+fallback) when there is no GPU.  No GPU compute here."""
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    pkg.build()
+    return pkg.load()
+
+
+def test_library_exports_every_declared_symbol(pkg, lib):
+    declared = pkg.declared_symbols()
+    assert len(declared) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.path], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in declared if s not in exported]
+    assert not missing, f"declared in include/bitnet_hip.h but not exported: {missing}"
+    for s in declared:
+        assert hasattr(lib.c, s)
+
+
+def test_no_torch_or_oracle_linked(lib):
+    """The boundary is plain C: no torch types, and the oracle is not linked in."""
+    out = subprocess.check_output(["ldd", lib.path], text=True)
+    assert "torch" not in out and "bitnet_oracle" not in out
+    assert "amdhip64" in out
+
+
+def test_argument_validation_matches_reference_wording(lib, pkg):
+    """Q/i2s_qk256.rs:691-742 substrings; checks run before any device work."""
+    z64, z128 = np.zeros(64, np.uint8), np.zeros(128, np.uint8)
+    with pytest.raises(pkg.BitNetHipError, match="x length") as e:
+        lib.gemv_qk256(z64, np.ones(246, np.float32), 1, 256, 64)
+    assert e.value.code == pkg.ERR_INVALID_ARGUMENT and e.value.kind == "InvalidArguments"
+    with pytest.raises(pkg.BitNetHipError, match="too short"):
+        lib.gemv_qk256(z64, np.ones(256, np.float32), 2, 256, 64)
+    with pytest.raises(pkg.BitNetHipError, match="y_out length"):
+        lib.gemv_qk256(z128, np.ones(256, np.float32), 2, 256, 64, y_len=1)
+    with pytest.raises(pkg.BitNetHipError, match="row bytes mismatch"):
+        lib.gemv_qk256(z128, np.ones(256, np.float32), 1, 256, 128)
+    # K/cpu/quantized_matmul.rs:705-742
+    a4, p4, s4 = np.ones(4, np.float32), np.zeros(4, np.uint8), np.ones(4, np.float32)
+    for m, n, k in [(0, 2, 2), (2, 0, 2), (2, 2, 0)]:
+        with pytest.raises(pkg.BitNetHipError, match="dimensions must be > 0"):
+            lib.i2s_matmul_f32(a4, p4, s4, m, n, k, 32, out_len=4)
+    with pytest.raises(pkg.BitNetHipError, match="block_size must be > 0"):
+        lib.i2s_matmul_f32(a4, p4[:2], s4[:2], 2, 2, 2, 0)
+    with pytest.raises(pkg.BitNetHipError, match="activations too small"):
+        lib.i2s_matmul_f32(a4[:2], p4, s4, 2, 2, 4, 32)
+    with pytest.raises(pkg.BitNetHipError, match="output too small"):
+        lib.i2s_matmul_f32(a4, p4[:2], s4[:2], 2, 2, 2, 32, out_len=1)
+    # K/cpu/fallback.rs:320-331, :351-360
+    with pytest.raises(pkg.BitNetHipError, match="dimension mismatch"):
+        lib.matmul_i2s([1, 2], [1, 0], 2, 2, 2, c_len=4)
+    with pytest.raises(pkg.BitNetHipError, match="too small"):
+        lib.quantize(np.ones(32, np.float32), out_len=1)
+    with pytest.raises(pkg.BitNetHipError, match="Invalid quantization type"):
+        lib.quantize(np.ones(32, np.float32), qtype=7)
+    with pytest.raises(pkg.BitNetHipError) as e:
+        lib.quantize(np.ones(32, np.float32), qtype=pkg.QTYPE_TL1)
+    assert e.value.kind == "UnsupportedHardware"
+    # K/cuda/qk256_gemv.rs:60-68
+    with pytest.raises(pkg.BitNetHipError, match="multiple of 256"):
+        lib.qk256_gemv(np.zeros(64, np.uint8), np.ones(1, np.float32), np.ones(255, np.float32), 1, 1, 255)
+    # Q/i2s_qk256.rs:499-541 size tolerance, surfaced at upload
+    with pytest.raises(pkg.BitNetHipError, match="data size mismatch"):
+        lib.weights_upload_qk256(np.zeros(512 * 256 + 129, np.uint8), 512, 1024, 256)
+    with pytest.raises(pkg.BitNetHipError, match="unknown weights handle"):
+        lib.weights_free(12345)
+
+
+def test_fails_loudly_without_gpu(lib, pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert not lib.is_available() and lib.device_count() == 0
+    with pytest.raises(pkg.BitNetHipError) as e:
+        lib.init(0)
+    assert e.value.kind == "GpuError"
+    # a valid call must NOT silently compute on the CPU
+    with pytest.raises(pkg.BitNetHipError) as e:
+        lib.gemv_qk256(np.full(64, 0xAA, np.uint8), np.ones(256, np.float32), 1, 256, 64)
+    assert e.value.kind == "GpuError"
+    with pytest.raises(pkg.BitNetHipError):
+        lib.matmul_i2s([1, 2, 3, 4], [1, 0, 0, 1], 2, 2, 2)
+
+
+def test_missing_library_raises(pkg, tmp_path):
+    with pytest.raises(FileNotFoundError, match="no fallback"):
+        pkg.HipLib(str(tmp_path / "nope.so"))
