@@ -23,7 +23,7 @@ HEADER_PATH = os.path.join(ROOT, "include", "bitnet_hip.h")
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_GPU, ERR_UNSUPPORTED, ERR_EXECUTION = -1, -2, -3, -4
-KERNEL_AUTO, KERNEL_EXACT, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_EXACT, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILED = 0, 1, 2, 3, 4
 QTYPE_I2S, QTYPE_TL1, QTYPE_TL2 = 0, 1, 2
 
 _u8p = C.POINTER(C.c_uint8)
@@ -110,6 +110,15 @@ class HipLib:
         L.bitnet_hip_weights_info.argtypes = [C.c_uint64, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]
         L.bitnet_hip_gemv_dev.argtypes = [C.c_uint64, _vp, _vp, _vp]
         L.bitnet_hip_matmul_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp]
+        L.bitnet_hip_weights_concat.argtypes = [C.POINTER(C.c_uint64), _sz, C.c_int, C.POINTER(C.c_uint64)]
+        L.bitnet_hip_gemv_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, _vp]
+        L.bitnet_hip_rmsnorm.argtypes = [_f32p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, C.c_float]
+        L.bitnet_hip_norm_rows_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, C.c_float, C.c_int, _vp]
+        L.bitnet_hip_embed_f16_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]
+        L.bitnet_hip_advance_pos_dev.argtypes = [_vp, _vp]
+        L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
+        L.bitnet_hip_logits_f16_dev.argtypes = [_vp, _vp, _vp, C.c_float, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_argmax_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp]
 
     # -- helpers ---------------------------------------------------------
     def last_error(self) -> str:
@@ -234,6 +243,41 @@ class HipLib:
     def matmul_dev(self, h: int, x, y, m: int, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_matmul_dev(h, _ptr(x), _ptr(y), m, _vp(stream)))
 
+    def weights_concat(self, parts, interleave16: bool = False) -> int:
+        arr = (C.c_uint64 * len(parts))(*parts)
+        h = C.c_uint64(0)
+        self._check(self.c.bitnet_hip_weights_concat(arr, len(parts), int(interleave16), C.byref(h)))
+        return h.value
+
+    def gemv_fused_dev(self, h: int, x, y, m: int = 1, ln_gamma=None, ln_eps: float = 0.0, residual=None, flags: int = 0, stream: int = 0) -> None:
+        self._check(
+            self.c.bitnet_hip_gemv_fused_dev(h, _ptr(x), _ptr(y), m, _ptr(ln_gamma) if ln_gamma is not None else None, ln_eps,
+                                             _ptr(residual) if residual is not None else None, flags, _vp(stream))
+        )
+
+    # -- decode-step operators ------------------------------------------------
+    def rmsnorm(self, x, gamma, num_rows: int, hidden: int, eps: float = 1e-6) -> np.ndarray:
+        xa, ga = _np(x, np.float32), _np(gamma, np.float32)
+        out = np.zeros(num_rows * hidden, np.float32)
+        self._check(self.c.bitnet_hip_rmsnorm(xa.ctypes.data_as(_f32p), xa.size, ga.ctypes.data_as(_f32p), ga.size, out.ctypes.data_as(_f32p), out.size, num_rows, hidden, eps))
+        return out
+
+    def norm_rows_dev(self, x, gamma, out, rows: int, hidden: int, eps: float, rms: bool, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_norm_rows_dev(_ptr(x), _ptr(gamma), _ptr(out), rows, hidden, eps, int(rms), _vp(stream)))
+
+    def embed_f16_dev(self, table, tokens, out, n: int, hidden: int, vocab: int, offset=None, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_embed_f16_dev(_ptr(table), _ptr(tokens), _ptr(offset) if offset is not None else None, n, hidden, vocab, _ptr(out), _vp(stream)))
+
+    def attention_decode_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, out, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_decode_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(out), _vp(stream)))
+
+    def logits_f16_dev(self, table, x, gamma, eps, hidden, vocab, logits, scratch, n_wg, token=None, pos=None, history=None, n_forced=None, stream: int = 0) -> None:
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._check(self.c.bitnet_hip_logits_f16_dev(_ptr(table), _ptr(x), opt(gamma), eps, hidden, vocab, _ptr(logits), _ptr(scratch), n_wg, opt(token), opt(pos), opt(history), opt(n_forced), _vp(stream)))
+
+    def argmax_dev(self, v, n: int, scratch, n_wg: int, token, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_argmax_dev(_ptr(v), n, _ptr(scratch), n_wg, _ptr(token), _vp(stream)))
+
 
 _lib = None
 
@@ -253,3 +297,121 @@ def declared_symbols() -> list[str]:
     text = open(HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bitnet_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+# ---------------------------------------------------------------------------
+# Host decode loop (C++ above the C ABI: bitnet-rs_amd/host/decoder.{hpp,cpp})
+# ---------------------------------------------------------------------------
+
+HOST_LIB_PATH = os.path.join(HERE, "libbitnet_host.so")
+
+
+class HostConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "ffn", "vocab", "max_pos")] + [
+        ("eps", C.c_float),
+        ("rope_theta", C.c_float),
+    ]
+
+
+class HostDecoder:
+    """ctypes view of the C++ Decoder (mirror of the reference's Rust-side
+    TransformerModel / KVCache / greedy loop).  No arithmetic here."""
+
+    def __init__(self, cfg, path: str = HOST_LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: build it with __graft_entry__.build() -- there is no fallback path")
+        load()  # the kernel library must be loadable first
+        self.c = C.CDLL(path)
+        L = self.c
+        L.bitnet_host_create.restype = C.c_void_p
+        L.bitnet_host_create.argtypes = [C.POINTER(HostConfig)]
+        L.bitnet_host_destroy.argtypes = [C.c_void_p]
+        L.bitnet_host_error.restype = C.c_char_p
+        L.bitnet_host_error.argtypes = [C.c_void_p]
+        L.bitnet_host_set_layer_qk256.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p] + [_u8p] * 7
+        L.bitnet_host_set_layer_i2s.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.POINTER(_u8p), C.POINTER(_f32p), _sz]
+        L.bitnet_host_set_globals.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), _f32p]
+        L.bitnet_host_reset.argtypes = [C.c_void_p]
+        L.bitnet_host_feed.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+        L.bitnet_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.bitnet_host_position.argtypes = [C.c_void_p]
+        L.bitnet_host_history.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+        L.bitnet_host_last_logits.argtypes = [C.c_void_p, _f32p]
+        L.bitnet_host_last_hidden.argtypes = [C.c_void_p, _f32p]
+        L.bitnet_host_probe_gateup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.bitnet_host_weight_bytes.argtypes = [C.c_void_p]
+        L.bitnet_host_weight_bytes.restype = C.c_uint64
+        self.cfg = cfg
+        hc = HostConfig(**{k: (float(v) if k in ("eps", "rope_theta") else int(v)) for k, v in cfg.asdict().items()})
+        self.h = L.bitnet_host_create(C.byref(hc))
+        err = self.error()
+        if err:
+            raise BitNetHipError(ERR_GPU, err)
+
+    def error(self) -> str:
+        e = self.c.bitnet_host_error(self.h)
+        return e.decode() if e else ""
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise BitNetHipError(rc, self.error() or f"bitnet_host rc={rc}")
+
+    def close(self) -> None:
+        if self.h:
+            self.c.bitnet_host_destroy(self.h)
+            self.h = None
+
+    def set_layer_qk256(self, layer: int, w: dict) -> None:
+        a = [_np(w["attn_norm"], np.float32), _np(w["ffn_norm"], np.float32)] + [_np(w[k], np.uint8) for k in ("q", "k", "v", "o", "gate", "up", "down")]
+        self._check(self.c.bitnet_host_set_layer_qk256(self.h, layer, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), *[x.ctypes.data_as(_u8p) for x in a[2:]]))
+
+    def set_layer_i2s(self, layer: int, w: dict, block: int) -> None:
+        names = ("q", "k", "v", "o", "gate", "up", "down")
+        ws = [_np(w[k], np.uint8) for k in names]
+        ss = [_np(w[k + "_scales"], np.float32) for k in names]
+        wp = (_u8p * 7)(*[x.ctypes.data_as(_u8p) for x in ws])
+        sp = (_f32p * 7)(*[x.ctypes.data_as(_f32p) for x in ss])
+        an, fn = _np(w["attn_norm"], np.float32), _np(w["ffn_norm"], np.float32)
+        self._check(self.c.bitnet_host_set_layer_i2s(self.h, layer, an.ctypes.data_as(_f32p), fn.ctypes.data_as(_f32p), wp, sp, block))
+
+    def set_globals(self, g: dict) -> None:
+        e, f = _np(g["embed_f16"], np.uint16), _np(g["final_norm"], np.float32)
+        self._check(self.c.bitnet_host_set_globals(self.h, e.ctypes.data_as(C.POINTER(C.c_uint16)), f.ctypes.data_as(_f32p)))
+
+    def reset(self) -> None:
+        self._check(self.c.bitnet_host_reset(self.h))
+
+    def feed(self, tokens) -> None:
+        t = _np(tokens, np.int32)
+        self._check(self.c.bitnet_host_feed(self.h, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size))
+
+    def run(self, n: int, with_logits: bool = True, use_graph: bool = True) -> float:
+        ms = C.c_float(0)
+        self._check(self.c.bitnet_host_run(self.h, n, int(with_logits), int(use_graph), C.byref(ms)))
+        return ms.value
+
+    def position(self) -> int:
+        return int(self.c.bitnet_host_position(self.h))
+
+    def history(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int32)
+        self._check(self.c.bitnet_host_history(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return out
+
+    def last_logits(self) -> np.ndarray:
+        out = np.zeros(self.cfg.vocab, np.float32)
+        self._check(self.c.bitnet_host_last_logits(self.h, out.ctypes.data_as(_f32p)))
+        return out
+
+    def last_hidden(self) -> np.ndarray:
+        out = np.zeros(self.cfg.hidden, np.float32)
+        self._check(self.c.bitnet_host_last_hidden(self.h, out.ctypes.data_as(_f32p)))
+        return out
+
+    def probe_gateup(self, reps: int):
+        us, b = C.c_float(0), C.c_double(0)
+        self._check(self.c.bitnet_host_probe_gateup(self.h, reps, C.byref(us), C.byref(b)))
+        return us.value, b.value
+
+    def weight_bytes(self) -> int:
+        return int(self.c.bitnet_host_weight_bytes(self.h))

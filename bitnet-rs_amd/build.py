@@ -47,7 +47,17 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag=True builds libbitnet_hip_diag.so with -DBH_STAMPS (in-kernel time stamps);
+    it is a developer tool and never what tests, smoke() or bench.py load."""
+    global OBJ_DIR, LIB_PATH
+    obj_dir = OBJ_DIR + ("_diag" if diag else "")
+    lib_path = LIB_PATH.replace(".so", "_diag.so") if diag else LIB_PATH
+    extra_all = ["-DBH_STAMPS"] if diag else []
+    return _build(force, verbose, obj_dir, lib_path, extra_all)
+
+
+def _build(force: bool, verbose: bool, OBJ_DIR: str, LIB_PATH: str, extra_all: list) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
@@ -59,7 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         spath = os.path.join(CSRC, src)
         if force or _stale(obj, [spath] + headers):
-            cmd = [HIPCC, *COMMON_FLAGS, *EXTRA.get(src, []), "-c", spath, "-o", obj]
+            cmd = [HIPCC, *COMMON_FLAGS, *extra_all, *EXTRA.get(src, []), "-c", spath, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -78,8 +88,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if not extra_all:
+        _build_host(force, verbose, LIB_PATH)
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB_PATH = os.path.join(HERE, "libbitnet_host.so")
+
+
+def _build_host(force: bool, verbose: bool, kernel_lib: str) -> str:
+    """The C++ host layer above the C ABI (decode loop, graph capture).  Plain host C++:
+    it only includes include/bitnet_hip.h and the HIP runtime API."""
+    srcs = [os.path.join(HOST_DIR, f) for f in sorted(os.listdir(HOST_DIR)) if f.endswith(".cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".hpp")]
+    deps += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)] + [kernel_lib]
+    if force or _stale(HOST_LIB_PATH, deps):
+        cmd = [
+            "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__",
+            f"-I{INCLUDE}", f"-I{HOST_DIR}", "-I/opt/rocm/include", *srcs, "-o", HOST_LIB_PATH,
+            f"-L{HERE}", "-lbitnet_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+        ]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return HOST_LIB_PATH
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

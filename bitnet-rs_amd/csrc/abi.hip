@@ -66,13 +66,23 @@ struct DevBuf {
     }
 };
 
-int run_gemv(const Weights &w, const float *x_dev, float *y_dev, size_t m, hipStream_t stream) {
+int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvFusion &fu, hipStream_t stream) {
     int kernel = g_kernel;
-    if (kernel == BITNET_HIP_KERNEL_AUTO || kernel == BITNET_HIP_KERNEL_MFMA)
-        kernel = valu_supported(w) ? BITNET_HIP_KERNEL_VALU : BITNET_HIP_KERNEL_EXACT;
+    if (kernel == BITNET_HIP_KERNEL_AUTO) kernel = BITNET_HIP_KERNEL_MFMA;
+    if ((kernel == BITNET_HIP_KERNEL_MFMA || kernel == BITNET_HIP_KERNEL_MFMA_TILED) && !mfma_supported(w))
+        kernel = BITNET_HIP_KERNEL_VALU;
     if (kernel == BITNET_HIP_KERNEL_VALU && !valu_supported(w)) kernel = BITNET_HIP_KERNEL_EXACT;
-    hipError_t e = kernel == BITNET_HIP_KERNEL_VALU ? launch_gemv_valu(w, x_dev, y_dev, m, stream)
-                                                    : launch_gemv_exact(w, x_dev, y_dev, m, stream);
+    if ((fu.ln_gamma || fu.residual || fu.silu_mul) && kernel != BITNET_HIP_KERNEL_MFMA && kernel != BITNET_HIP_KERNEL_MFMA_TILED)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "fused LayerNorm/residual needs the MFMA GEMV (shape %zux%zu unsupported)", w.rows, w.cols);
+    hipError_t e;
+    if (kernel == BITNET_HIP_KERNEL_MFMA_TILED || kernel == BITNET_HIP_KERNEL_MFMA) {
+        e = build_tiles(w, stream);  // no-op after the first call (done at upload normally)
+        if (e == hipSuccess) e = launch_gemv_mfma(w, x_dev, y_dev, m, fu, stream);
+    } else if (kernel == BITNET_HIP_KERNEL_VALU) {
+        e = launch_gemv_valu(w, x_dev, y_dev, m, stream);
+    } else {
+        e = launch_gemv_exact(w, x_dev, y_dev, m, stream);
+    }
     if (e != hipSuccess)
         return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
@@ -168,7 +178,7 @@ int bitnet_hip_get_device_info(int device, bitnet_hip_device_info *out) {
 }
 
 int bitnet_hip_set_kernel(int kernel) {
-    if (kernel < BITNET_HIP_KERNEL_AUTO || kernel > BITNET_HIP_KERNEL_MFMA)
+    if (kernel < BITNET_HIP_KERNEL_AUTO || kernel > BITNET_HIP_KERNEL_MFMA_TILED)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
     g_kernel = kernel;
     return BITNET_HIP_OK;
@@ -217,6 +227,10 @@ int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_
         free_weights(w);
         return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy H2D failed for QK256 codes");
     }
+    if (mfma_supported(*w) && (build_tiles(*w, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "re-tiling QK256 codes for the MFMA kernel failed");
+    }
     return register_weights(w, out);
     BH_GUARD_END
 }
@@ -258,6 +272,10 @@ int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, c
         free_weights(w);
         return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy H2D failed for I2_S weights");
     }
+    if (mfma_supported(*w) && (build_tiles(*w, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+        free_weights(w);
+        return set_error(BITNET_HIP_ERR_GPU, "re-tiling I2_S codes for the MFMA kernel failed");
+    }
     return register_weights(w, out);
     BH_GUARD_END
 }
@@ -298,7 +316,179 @@ int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_d
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_dev");
     if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
-    return run_gemv(*w, x_dev, y_dev, m, (hipStream_t)stream);
+    return run_gemv(*w, x_dev, y_dev, m, GemvFusion(), (hipStream_t)stream);
+    BH_GUARD_END
+}
+
+int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m,
+                              const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags,
+                              void *stream) {
+    BH_GUARD_BEGIN
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_fused_dev");
+    if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    GemvFusion fu;
+    fu.ln_gamma = ln_gamma_dev;
+    fu.ln_eps = ln_eps;
+    fu.residual = residual_dev;
+    fu.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    if (fu.silu_mul && (!w->paired || residual_dev))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    return run_gemv(*w, x_dev, y_dev, m, fu, (hipStream_t)stream);
+    BH_GUARD_END
+}
+
+int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts, int interleave16,
+                              bitnet_hip_weights_t *out) {
+    BH_GUARD_BEGIN
+    if (!parts || !out || n_parts == 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_concat");
+    std::vector<Weights *> ws;
+    size_t rows = 0;
+    for (size_t i = 0; i < n_parts; ++i) {
+        Weights *w = lookup(parts[i]);
+        if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)parts[i]);
+        if (i > 0 && (w->cols != ws[0]->cols || w->row_stride_bytes != ws[0]->row_stride_bytes || w->lut != ws[0]->lut ||
+                      w->block_size != ws[0]->block_size || (w->scales == nullptr) != (ws[0]->scales == nullptr)))
+            return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_concat: part %zu differs in cols / code map / scales", i);
+        ws.push_back(w);
+        rows += w->rows;
+    }
+    if (interleave16 && (n_parts != 2 || ws[0]->rows != ws[1]->rows || ws[0]->rows % 16 != 0))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_concat: interleave16 needs two parts of equal rows %% 16 == 0");
+    Weights *f = new Weights();
+    *f = *ws[0];
+    f->codes = nullptr;
+    f->scales = nullptr;
+    f->tiles = nullptr;
+    f->rows = rows;
+    f->paired = interleave16 != 0;
+    f->algorithmic_bytes = 0;
+    for (Weights *w : ws) f->algorithmic_bytes += w->algorithmic_bytes;
+    const size_t stride = f->row_stride_bytes, sstride = f->nblk * sizeof(float);
+    bool ok = hipMalloc((void **)&f->codes, rows * stride + 16) == hipSuccess;
+    if (ok && ws[0]->scales) ok = hipMalloc((void **)&f->scales, rows * sstride) == hipSuccess;
+    if (ok && interleave16) {
+        const size_t nt = ws[0]->rows / 16;
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = hipMemcpy2D(f->codes + i * 16 * stride, 32 * stride, ws[i]->codes, 16 * stride, 16 * stride, nt,
+                             hipMemcpyDeviceToDevice) == hipSuccess;
+            if (ok && f->scales)
+                ok = hipMemcpy2D((uint8_t *)f->scales + i * 16 * sstride, 32 * sstride, ws[i]->scales, 16 * sstride,
+                                 16 * sstride, nt, hipMemcpyDeviceToDevice) == hipSuccess;
+        }
+    } else if (ok) {
+        size_t r0 = 0;
+        for (Weights *w : ws) {
+            ok = ok && hipMemcpy(f->codes + r0 * stride, w->codes, w->rows * stride, hipMemcpyDeviceToDevice) == hipSuccess;
+            if (ok && f->scales)
+                ok = hipMemcpy((uint8_t *)f->scales + r0 * sstride, w->scales, w->rows * sstride, hipMemcpyDeviceToDevice) == hipSuccess;
+            r0 += w->rows;
+        }
+    }
+    if (ok && mfma_supported(*f)) ok = build_tiles(*f, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        free_weights(f);
+        return set_error(BITNET_HIP_ERR_GPU, "weights_concat: device allocation or copy failed");
+    }
+    return register_weights(f, out);
+    BH_GUARD_END
+}
+
+/* ------------------------------------------------ decode-step operators */
+
+int bitnet_hip_norm_rows_dev(const float *x_dev, const float *gamma_dev, float *out_dev, size_t rows, size_t hidden,
+                             float eps, int rms, void *stream) {
+    BH_GUARD_BEGIN
+    if (!x_dev || !gamma_dev || !out_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to norm_rows_dev");
+    if (hidden == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "hidden_dim must be > 0");
+    BH_HIP_TRY(launch_norm_rows(x_dev, gamma_dev, out_dev, (int)rows, (int)hidden, eps, rms != 0, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_rmsnorm(const float *input, size_t in_len, const float *gamma, size_t gamma_len, float *output,
+                       size_t out_len, size_t num_rows, size_t hidden_dim, float eps) {
+    BH_GUARD_BEGIN
+    if (!input || !gamma || !output) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to rmsnorm");
+    if (hidden_dim == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "hidden_dim must be > 0");
+    if (in_len < num_rows * hidden_dim || out_len < num_rows * hidden_dim || gamma_len < hidden_dim)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "rmsnorm: buffer too small for %zu rows x %zu", num_rows, hidden_dim);
+    if (num_rows == 0) return BITNET_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf xd, gd, od;
+    const size_t n = num_rows * hidden_dim * 4;
+    if (xd.alloc(n) != hipSuccess || gd.alloc(hidden_dim * 4) != hipSuccess || od.alloc(n) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in rmsnorm");
+    BH_HIP_TRY(hipMemcpy(xd.p, input, n, hipMemcpyHostToDevice));
+    BH_HIP_TRY(hipMemcpy(gd.p, gamma, hidden_dim * 4, hipMemcpyHostToDevice));
+    BH_HIP_TRY(launch_norm_rows(xd.as<float>(), gd.as<float>(), od.as<float>(), (int)num_rows, (int)hidden_dim, eps, true, nullptr));
+    BH_HIP_TRY(hipMemcpy(output, od.p, n, hipMemcpyDeviceToHost));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!pos_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to advance_pos_dev");
+    BH_HIP_TRY(launch_advance_pos(pos_dev, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_embed_f16_dev(const void *table, const int32_t *tokens_dev, const int32_t *offset_dev, size_t n,
+                             size_t hidden, size_t vocab, float *out_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!table || !tokens_dev || !out_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to embed_f16_dev");
+    if (hidden % 8 != 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "embed: hidden %zu must be a multiple of 8", hidden);
+    BH_HIP_TRY(launch_embed_f16(table, tokens_dev, offset_dev, (int)n, (int)hidden, (int)vocab, out_dev, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                                    float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                    const int32_t *pos_dev, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_dev");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim == 0 || head_dim > 128 || 256 % head_dim != 0 || head_dim % 8 != 0)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu unsupported (32/64/128)", head_dim);
+    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                  (int)max_pos, pos_dev, out, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_logits_f16_dev(const void *table, const float *x, const float *gamma, float eps, size_t hidden, size_t vocab,
+                              float *logits, void *scratch, size_t n_wg, int32_t *token_dev, int32_t *pos_dev,
+                              int32_t *history_dev, const int32_t *n_forced_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!table || !x || !logits || !scratch) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to logits_f16_dev");
+    if (hidden % 512 != 0 || hidden > 8192) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "logits: hidden %zu must be a multiple of 512, <= 8192", hidden);
+    if (n_wg == 0 || n_wg > 65535) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "logits: bad workgroup count %zu", n_wg);
+    float *bv = static_cast<float *>(scratch);
+    int *bi = reinterpret_cast<int *>(bv + n_wg);
+    BH_HIP_TRY(launch_logits_f16(table, x, gamma, eps, (int)hidden, (int)vocab, logits, bv, bi, (int)n_wg, (hipStream_t)stream));
+    if (token_dev || pos_dev)
+        BH_HIP_TRY(launch_argmax_final(bv, bi, (int)n_wg, token_dev, pos_dev, history_dev, n_forced_dev, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_argmax_dev(const float *v, size_t n, void *scratch, size_t n_wg, int32_t *token_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!v || !scratch || !token_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to argmax_dev");
+    if (n == 0 || n_wg == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "argmax: empty input");
+    float *bv = static_cast<float *>(scratch);
+    int *bi = reinterpret_cast<int *>(bv + n_wg);
+    BH_HIP_TRY(launch_argmax(v, (int)n, bv, bi, (int)n_wg, token_dev, (hipStream_t)stream));
+    return BITNET_HIP_OK;
     BH_GUARD_END
 }
 
@@ -477,5 +667,14 @@ int bitnet_hip_dequant_i2s(const uint8_t *bytes, size_t bytes_len, size_t rows, 
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
+
+#ifdef BH_STAMPS
+/* Diagnostic build only (not declared in include/bitnet_hip.h, absent from the
+ * production library): device buffer of 8 x u64 per workgroup for in-kernel stamps. */
+int bitnet_hip_debug_set_stamps(void *dev_buffer) {
+    bitnet_hip::g_mfma_stamps = static_cast<unsigned long long *>(dev_buffer);
+    return BITNET_HIP_OK;
+}
+#endif
 
 }  // extern "C"

@@ -64,6 +64,15 @@ struct Weights {
     // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
     uint8_t *tiles = nullptr;
     size_t n_row_tiles = 0, n_kblocks = 0;
+    bool paired = false;  // rows are interleaved (gate tile, up tile) pairs (weights_concat interleave16)
+};
+
+// Optional work fused around a GEMV launch (MFMA kernel only).
+struct GemvFusion {
+    const float *ln_gamma = nullptr;  // LayerNorm(no bias, mean-subtracting) prologue on x
+    float ln_eps = 0.0f;
+    const float *residual = nullptr;  // y = residual + W x
+    bool silu_mul = false;            // rows are (gate tile, up tile) pairs: y = silu(gate) * up
 };
 
 // ---- kernel launchers (kernels_*.hip) -------------------------------------
@@ -72,11 +81,31 @@ struct Weights {
 hipError_t launch_gemv_exact(const Weights &w, const float *x, float *y, size_t m, hipStream_t stream);
 hipError_t launch_gemv_valu(const Weights &w, const float *x, float *y, size_t m, hipStream_t stream);
 bool valu_supported(const Weights &w);
+hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu,
+                            hipStream_t stream);
+bool mfma_supported(const Weights &w);
+hipError_t build_tiles(Weights &w, hipStream_t stream);
+extern unsigned long long *g_mfma_stamps;  // diagnostic build only
 hipError_t launch_matmul_i2s_u8(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n,
                                 size_t k, hipStream_t stream);
 hipError_t launch_quantize_i2s(const float *in, size_t n, uint8_t *out, size_t out_len, float *scales,
                                hipStream_t stream);
 hipError_t launch_dequant_i2s(const uint8_t *bytes, size_t rows, size_t cols, size_t block, int inv,
                               float k, int transposed, float *out, hipStream_t stream);
+
+hipError_t launch_embed_f16(const void *table, const int *tokens, const int *offset_ptr, int n, int hidden,
+                            int vocab, float *out, hipStream_t stream);
+hipError_t launch_advance_pos(int *pos_ptr, hipStream_t stream);
+hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int rows, int hidden, float eps,
+                            bool rms, hipStream_t stream);
+hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                              float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
+                              float *out, hipStream_t stream);
+hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,
+                             float *logits, float *best_val, int *best_idx, int n_wg, hipStream_t stream);
+hipError_t launch_argmax_final(const float *best_val, const int *best_idx, int n, int *token_out, int *pos_ptr,
+                               int *history, const int *n_forced, hipStream_t stream);
+hipError_t launch_argmax(const float *v, int n, float *best_val, int *best_idx, int n_wg, int *token_out,
+                         hipStream_t stream);
 
 }  // namespace bitnet_hip

@@ -1,0 +1,380 @@
+// kernels_decode.hip -- the decode-step operators around the I2_S GEMVs (gfx950):
+// embedding gather, LayerNorm / RMSNorm rows, RoPE + KV append + GQA attention for
+// one new token, tied-embedding logits (f16 table, f32 accumulate) with fused final
+// norm and greedy argmax.  Semantics follow the reference's transformer
+// (T = crates/bitnet-transformer/src/lib.rs); see oracle/transformer_oracle.c.
+//
+// Position and token live in device memory (pos_ptr / token_ptr) so one captured
+// hipGraph replays for every decode step without host round trips.
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// 256-thread block reductions; slot = 4 floats of LDS.
+__device__ __forceinline__ float bsum(float v, float *slot) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+}
+__device__ __forceinline__ float bmax(float v, float *slot) {
+    v = wmax(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+}
+
+// ---- embedding: row gather from the f16 table (T:1415-1424) -------------------------
+__global__ void k_embed_f16(const _Float16 *__restrict__ table, const int *__restrict__ tokens,
+                            const int *__restrict__ offset_ptr, int n, int hidden, int vocab,
+                            float *__restrict__ out) {
+    const int per_row = hidden >> 3;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * per_row) return;
+    const int t = gid / per_row, c = gid % per_row;
+    int tok = tokens[t + (offset_ptr ? *offset_ptr : 0)];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const half8 h = *reinterpret_cast<const half8 *>(table + (size_t)tok * hidden + 8 * c);
+    float *o = out + (size_t)t * hidden + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+}
+
+hipError_t launch_embed_f16(const void *table, const int *tokens, const int *offset_ptr, int n, int hidden,
+                            int vocab, float *out, hipStream_t stream) {
+    const int total = n * (hidden >> 3);
+    hipLaunchKernelGGL(k_embed_f16, dim3((total + 255) / 256), dim3(256), 0, stream,
+                       static_cast<const _Float16 *>(table), tokens, offset_ptr, n, hidden, vocab, out);
+    return hipGetLastError();
+}
+
+// ---- LayerNorm (no bias, mean-subtracting; T:67-100) / RMSNorm (K/rocm/rmsnorm.rs) -----
+// One 256-thread workgroup per row.
+template <bool RMS>
+__global__ __launch_bounds__(256) void k_norm_rows(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                   float *__restrict__ out, int hidden, float eps) {
+    __shared__ float slot[4];
+    const float *xr = x + (size_t)blockIdx.x * hidden;
+    float *orow = out + (size_t)blockIdx.x * hidden;
+    float mean = 0.0f;
+    if (!RMS) {
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < hidden; i += 256) s += xr[i];
+        mean = bsum(s, slot) / (float)hidden;
+    }
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < hidden; i += 256) {
+        const float d = xr[i] - mean;
+        ss += d * d;
+    }
+    const float denom = sqrtf(bsum(ss, slot) / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += 256) orow[i] = (xr[i] - mean) / denom * gamma[i];
+}
+
+hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int rows, int hidden, float eps,
+                            bool rms, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (rms)
+        hipLaunchKernelGGL(k_norm_rows<true>, dim3(rows), dim3(256), 0, stream, x, gamma, out, hidden, eps);
+    else
+        hipLaunchKernelGGL(k_norm_rows<false>, dim3(rows), dim3(256), 0, stream, x, gamma, out, hidden, eps);
+    return hipGetLastError();
+}
+
+// ---- one-token attention: RoPE (T:134-163) + KV append (T:1171-1202) + GQA softmax
+//      attention (T:410-533).  One workgroup per query head. -------------------------------
+// qkv: [n_heads*D | n_kv*D | n_kv*D] raw projections of the new token.
+// kcache/vcache: [n_kv][max_pos][D] f32 for this layer.  *pos_ptr = number of cached tokens.
+__global__ __launch_bounds__(256) void k_attn_decode(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
+                                                     const float *__restrict__ rope_cos, float *__restrict__ kcache,
+                                                     float *__restrict__ vcache, int n_heads, int n_kv, int D,
+                                                     int max_pos, const int *__restrict__ pos_ptr,
+                                                     float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int pos = *pos_ptr;
+    const int t_k = pos + 1;
+    const int h = blockIdx.x, group = n_heads / n_kv, kvh = h / group, half = D >> 1;
+    float *qs = sm;            // [D] rotated query
+    float *kn = qs + D;        // [D] rotated new key
+    float *vn = kn + D;        // [D] new value
+    float *slot = vn + D;      // [4]
+    float *red = slot + 4;     // [2*D] halves of P.V
+    float *sc = red + 2 * D;   // [t_k] scores -> probabilities
+    const int tid = threadIdx.x;
+    const float *q_raw = qkv + (size_t)h * D;
+    const float *k_raw = qkv + (size_t)n_heads * D + (size_t)kvh * D;
+    const float *v_raw = qkv + (size_t)(n_heads + n_kv) * D + (size_t)kvh * D;
+    const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
+    if (tid < half) {
+        const float s = sr[tid], c = cr[tid];
+        const float q0 = q_raw[tid], q1 = q_raw[half + tid];
+        qs[tid] = q0 * c - q1 * s;
+        qs[half + tid] = q0 * s + q1 * c;
+        const float k0 = k_raw[tid], k1 = k_raw[half + tid];
+        kn[tid] = k0 * c - k1 * s;
+        kn[half + tid] = k0 * s + k1 * c;
+    }
+    if (tid < D) vn[tid] = v_raw[tid];
+    __syncthreads();
+    float *kc = kcache + (size_t)kvh * max_pos * D, *vc = vcache + (size_t)kvh * max_pos * D;
+    if (h % group == 0 && tid < D) {  // one workgroup per KV head appends
+        kc[(size_t)pos * D + tid] = kn[tid];
+        vc[(size_t)pos * D + tid] = vn[tid];
+    }
+    const float scale = 1.0f / sqrtf((float)D);
+    float mx = -INFINITY;
+    for (int j = tid; j < t_k; j += 256) {
+        const float *kr = j == pos ? kn : kc + (size_t)j * D;
+        float s = 0.0f;
+        for (int d = 0; d < D; d += 4) {
+            const float4 kv4 = *reinterpret_cast<const float4 *>(kr + d);
+            s += qs[d] * kv4.x;
+            s += qs[d + 1] * kv4.y;
+            s += qs[d + 2] * kv4.z;
+            s += qs[d + 3] * kv4.w;
+        }
+        s *= scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = bmax(mx, slot);
+    float sum = 0.0f;
+    for (int j = tid; j < t_k; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = bsum(sum, slot);
+    for (int j = tid; j < t_k; j += 256) sc[j] = sc[j] / sum;
+    __syncthreads();
+    // P.V: thread (d, part) accumulates positions j = part, part + nparts, ...
+    const int nparts = 256 / D, d = tid % D, part = tid / D;
+    if (part < nparts) {
+        float acc = 0.0f;
+        for (int j = part; j < t_k; j += nparts) {
+            const float v = j == pos ? vn[d] : vc[(size_t)j * D + d];
+            acc += sc[j] * v;
+        }
+        red[part * D + d] = acc;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float acc = red[tid];
+        for (int pI = 1; pI < nparts; ++pI) acc += red[pI * D + tid];
+        out[(size_t)h * D + tid] = acc;
+    }
+}
+
+hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                              float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
+                              float *out, hipStream_t stream) {
+    if (D > 128 || 256 % D != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(3 * D + 4 + 2 * D + max_pos) * sizeof(float);
+    static size_t lds_allowed = 64 * 1024;  // raised once, outside any stream capture
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_decode),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(256), lds, stream, qkv, rope_sin, rope_cos, kcache, vcache,
+                       n_heads, n_kv, D, max_pos, pos_ptr, out);
+    return hipGetLastError();
+}
+
+// ---- tied-embedding logits (T:1599-1630) with fused final LayerNorm and per-workgroup
+//      argmax partials (crates/bitnet-cli/src/sampling.rs:189-202) ----------------------------
+// logits[v] = sum_k LN(x)[k] * (float)E[v,k].  One wave per vocabulary row, grid-strided;
+// each lane keeps its slice of LN(x) in registers (hidden <= 8192).
+constexpr int kLogitChunks = 16;  // 512 columns each
+
+__global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__ table, const float *__restrict__ x,
+                                                    const float *__restrict__ gamma, float eps, int hidden, int vocab,
+                                                    float *__restrict__ logits, float *__restrict__ best_val,
+                                                    int *__restrict__ best_idx) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [hidden] normalised activations
+    __shared__ float slot[4];
+    __shared__ float wbv[4];
+    __shared__ int wbi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // final norm (T:1589), recomputed per workgroup: 10 KB from L2
+    float s = 0.0f;
+    for (int i = tid; i < hidden; i += 256) s += x[i];
+    const float mean = gamma ? bsum(s, slot) / (float)hidden : 0.0f;
+    float ss = 0.0f;
+    for (int i = tid; i < hidden; i += 256) {
+        const float d = x[i] - mean;
+        ss += d * d;
+    }
+    const float denom = gamma ? sqrtf(bsum(ss, slot) / (float)hidden + eps) : 1.0f;
+    for (int i = tid; i < hidden; i += 256) xs[i] = gamma ? (x[i] - mean) / denom * gamma[i] : x[i];
+    __syncthreads();
+    const int nchunks = hidden >> 9;  // 512 columns per chunk (hidden % 512 == 0)
+    float xr[kLogitChunks][8];
+#pragma unroll
+    for (int c = 0; c < kLogitChunks; ++c)
+        if (c < nchunks) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[c][i] = xs[512 * c + 8 * lane + i];
+        }
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    const int total_waves = gridDim.x * 4;
+    for (int row = blockIdx.x * 4 + wave; row < vocab; row += total_waves) {
+        const _Float16 *er = table + (size_t)row * hidden + 8 * lane;
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < kLogitChunks; ++c)
+            if (c < nchunks) {
+                const half8 e = *reinterpret_cast<const half8 *>(er + 512 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += xr[c][i] * (float)e[i];
+            }
+        acc = wsum(acc);
+        if (lane == 0) {
+            logits[row] = acc;
+            const float v = acc != acc ? -INFINITY : acc;  // NaN -> -inf (sampling.rs:45-49)
+            if (v > bv || (v == bv && row < bi)) {
+                bv = v;
+                bi = row;
+            }
+        }
+    }
+    if (lane == 0) {
+        wbv[wave] = bv;
+        wbi[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (wbv[w] > bv || (wbv[w] == bv && wbi[w] < bi)) {
+                bv = wbv[w];
+                bi = wbi[w];
+            }
+        best_val[blockIdx.x] = bv;
+        best_idx[blockIdx.x] = bi;
+    }
+}
+
+// Reduce the per-workgroup partials, write the token, advance the position.
+__global__ __launch_bounds__(256) void k_argmax_final(const float *__restrict__ best_val, const int *__restrict__ best_idx,
+                                                      int n, int *__restrict__ token_out, int *__restrict__ pos_ptr,
+                                                      int *__restrict__ history, const int *__restrict__ n_forced) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = best_val[i];
+        const int idx = best_idx[i];
+        if (v > bv || (v == bv && idx < bi)) {
+            bv = v;
+            bi = idx;
+        }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float v = sv[threadIdx.x + off];
+            const int idx = si[threadIdx.x + off];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && idx < si[threadIdx.x])) {
+                sv[threadIdx.x] = v;
+                si[threadIdx.x] = idx;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int tok = si[0] == 0x7fffffff ? 0 : si[0];
+        if (token_out) *token_out = tok;
+        if (pos_ptr) {
+            const int p = *pos_ptr;
+            // the token at position p+1 is the prediction unless the caller forces it (prompt)
+            if (history && (!n_forced || p + 1 >= *n_forced)) history[p + 1] = tok;
+            *pos_ptr = p + 1;
+        }
+    }
+}
+
+hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,
+                             float *logits, float *best_val, int *best_idx, int n_wg, hipStream_t stream) {
+    if (hidden % 512 != 0 || hidden > 512 * kLogitChunks) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_logits_f16, dim3(n_wg), dim3(256), (size_t)hidden * sizeof(float), stream,
+                       static_cast<const _Float16 *>(table), x, gamma, eps, hidden, vocab, logits, best_val, best_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax_final(const float *best_val, const int *best_idx, int n, int *token_out, int *pos_ptr,
+                               int *history, const int *n_forced, hipStream_t stream) {
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, stream, best_val, best_idx, n, token_out, pos_ptr, history,
+                       n_forced);
+    return hipGetLastError();
+}
+
+// Advance the position without sampling (prompt positions whose logits nobody reads).
+__global__ void k_advance_pos(int *pos_ptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *pos_ptr = *pos_ptr + 1;
+}
+hipError_t launch_advance_pos(int *pos_ptr, hipStream_t stream) {
+    hipLaunchKernelGGL(k_advance_pos, dim3(1), dim3(64), 0, stream, pos_ptr);
+    return hipGetLastError();
+}
+
+// Plain argmax over a logits vector (host-visible entry point).
+__global__ __launch_bounds__(256) void k_argmax_partial(const float *__restrict__ v, int n, float *__restrict__ best_val,
+                                                        int *__restrict__ best_idx) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float a = v[i] != v[i] ? -INFINITY : v[i];
+        if (a > bv || (a == bv && i < bi)) {
+            bv = a;
+            bi = i;
+        }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float a = sv[threadIdx.x + off];
+            const int idx = si[threadIdx.x + off];
+            if (a > sv[threadIdx.x] || (a == sv[threadIdx.x] && idx < si[threadIdx.x])) {
+                sv[threadIdx.x] = a;
+                si[threadIdx.x] = idx;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        best_val[blockIdx.x] = sv[0];
+        best_idx[blockIdx.x] = si[0];
+    }
+}
+
+hipError_t launch_argmax(const float *v, int n, float *best_val, int *best_idx, int n_wg, int *token_out,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_argmax_partial, dim3(n_wg), dim3(256), 0, stream, v, n, best_val, best_idx);
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, stream, best_val, best_idx, n_wg, token_out, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace bitnet_hip

@@ -1,0 +1,433 @@
+// kernels_mfma.hip -- the streaming I2_S / QK256 GEMV for MI355X (gfx950).
+//
+// Why matrix cores for a batch-1 GEMV (DESIGN.md "VALU budget"): at 2 bits per
+// weight the HBM roofline delivers 32 weights per byte, i.e. ~57 weights per clock
+// per CU at 8 TB/s, while a CU retires 128 vector lane-ops per clock.  Unpack +
+// convert + FMA on the vector ALUs costs >= 2.75 lane-ops per weight
+// (kernels_valu.hip) -- above the roofline time.  Here the vector ALUs only expand
+// 2-bit codes to int8 (11 instructions per 16 weights, v_perm_b32 as a 4-entry LUT)
+// and v_mfma_i32_16x16x64_i8 does every multiply-add.
+//
+// Exactness: activations are converted once per launch to 30-bit fixed point with
+// one power-of-two scale per activation row (q = rint(x * 2^(29-E)), |q| <= 2^30)
+// and split into four balanced base-256 digits d0..d3 in [-128,127].  The four
+// digit planes are four B-matrix columns of the MFMA, so
+//     sum_k w[r,k] * x[k]  =  2^(E-29) * sum_d 256^d * (sum_k w[r,k] * d_d[k])
+// with every inner sum an exact int32.  Only the final 4-term combine rounds
+// (<= 2 ulp): closer to the real-number result than the reference's own f32 loops,
+// and bit-reproducible for any tiling / K split / sharding.  Elements more than 2^6
+// below the row maximum are rounded at 2^-30 of that maximum.
+//
+// Layout: the codes are re-tiled once at upload into [row tile][256-col block]
+// tiles of 1 KiB = one coalesced global_load_dwordx4 per wave (lane l: row l&15,
+// 16-byte segment l>>4 of the 64-byte QK256 block), feeding four MFMAs.  Inside
+// each dword the sixteen 2-bit fields are transposed 4x4 so that
+// (w >> 2i) & 0x03030303 yields elements 4i..4i+3 in byte order, i.e. the A operand
+// comes out in natural K order and the activation digit planes are stored in
+// natural order too.
+//
+// Launch latency: every launch starts with a cold instruction cache on this chip
+// (measured: ~30-90 ns per 64-byte line of straight-line code), so the kernel is
+// written for a small instruction footprint: a 4-deep register ring of weight tiles
+// instead of a fully unrolled K loop, runtime flags instead of template variants.
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// In-kernel time stamps (s_memrealtime, 100 MHz) for the diagnostic build only; the
+// production library is compiled without BH_STAMPS and carries none of this.
+#ifdef BH_STAMPS
+#define BH_STAMP(i)                                                                    \
+    do {                                                                               \
+        if (p.stamps && threadIdx.x == 0) {                                            \
+            p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            if ((i) == 0) p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime(); \
+            if ((i) == 5) p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime(); \
+        }                                                                              \
+    } while (0)
+#else
+#define BH_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
+constexpr int kRing = 4;   // weight tiles (1 KiB each) a wave keeps in flight
+constexpr int kNVMAX = 8;  // float4 activation vectors per thread: K <= 8192
+
+struct MfmaArgs {
+    const uint8_t *tiles;  // [n_tiles][nblk][64 lanes][16 B], fields transposed (k_retile)
+    int rows, cols, nblk;  // nblk = ceil(cols / 256)
+    uint32_t lut;
+    int ksplit;            // 1, 2 or 4 K ranges per row tile (waves of one workgroup)
+    const float *x;        // [mt, cols]
+    float *y;              // [mt, rows]  (silu_mul: [mt, rows/2])
+    const float *ln_gamma; // optional LayerNorm prologue (T:67-100 semantics)
+    float ln_eps;
+    const float *residual; // optional: y = residual + W x
+    const float *wscale;   // optional f32 scale per (row, 256-block)
+    int silu_mul;          // rows are (gate tile, up tile) pairs: y = silu(gate) * up
+    unsigned long long *stamps;  // diagnostic builds only
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// Block-wide reductions over 4 waves; `slot` is a 4-float LDS scratch.
+__device__ __forceinline__ float block_sum(float v, float *slot) {
+    v = wave_sum_f(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+}
+__device__ __forceinline__ float block_max(float v, float *slot) {
+    v = wave_max_f(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+}
+
+// One dword = 16 codes (already field-transposed) -> the A operand of one MFMA:
+// register i, byte b <- LUT[code of element 4i+b].
+__device__ __forceinline__ v4i decode16(uint32_t w, uint32_t lut) {
+    v4i a;
+    a[0] = (int)__builtin_amdgcn_perm(0u, lut, w & 0x03030303u);
+    a[1] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 2) & 0x03030303u);
+    a[2] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 4) & 0x03030303u);
+    a[3] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 6) & 0x03030303u);
+    return a;
+}
+
+// 30-bit fixed point -> four balanced base-256 digits, one byte lane each.
+__device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &d0, uint32_t &d1,
+                                            uint32_t &d2, uint32_t &d3) {
+    int q = __float2int_rn(v * sc);
+    const int e0 = (int)(int8_t)q;
+    q = (q - e0) >> 8;
+    const int e1 = (int)(int8_t)q;
+    q = (q - e1) >> 8;
+    const int e2 = (int)(int8_t)q;
+    q = (q - e2) >> 8;
+    d0 |= (uint32_t)(e0 & 0xff) << (8 * b);
+    d1 |= (uint32_t)(e1 & 0xff) << (8 * b);
+    d2 |= (uint32_t)(e2 & 0xff) << (8 * b);
+    d3 |= (uint32_t)(q & 0xff) << (8 * b);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int ps = p.nblk * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
+    uint8_t *planes = lds;                                          // [4*MT][ps]
+    float *scratch = reinterpret_cast<float *>(lds + 4 * MT * ps);  // 4 reduce slots
+    float *inv_s = scratch + 4;                                     // [MT] (padded to 4)
+    float *part = scratch + 8;                                      // [4 waves][MT][16]
+    BH_STAMP(0);
+
+    // ---- wave -> (row tile, K range) ------------------------------------------------
+    const int tiles_per_wg = 4 / p.ksplit;
+    const int n_tiles = (p.rows + 15) >> 4;
+    int tile = blockIdx.x * tiles_per_wg + wave / p.ksplit;
+    tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
+    const int kpart = wave % p.ksplit;
+    const int b0 = (kpart * p.nblk) / p.ksplit, b1 = ((kpart + 1) * p.nblk) / p.ksplit;
+
+    // ---- 1. activation row 0: global -> registers.  Issued before the weight loads
+    //         because vmcnt retires in order and these come from L2. ------------------
+    const int nvec = (p.cols + 3) >> 2;
+    float4 xr[kNVMAX], gr[kNVMAX];
+    const int nv_iters = (nvec + 255) >> 8;  // wave-uniform: unused unrolled iterations are branched over
+    auto load_vec = [&](const float *src, float4 (&dst)[kNVMAX]) {
+#pragma unroll
+        for (int i = 0; i < kNVMAX; ++i) {
+            float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < nv_iters) {
+                const int idx = tid + 256 * i;
+                if (idx < nvec) v = *reinterpret_cast<const float4 *>(src + 4 * idx);  // cols % 4 == 0
+            }
+            dst[i] = v;
+        }
+    };
+    load_vec(p.x, xr);
+    if (p.ln_gamma) load_vec(p.ln_gamma, gr);
+
+    // ---- 2. weight tiles: ring of kRing 1-KiB tiles in flight per wave ---------------
+    const uint8_t *wbase = p.tiles + ((size_t)tile * p.nblk * 64 + lane) * 16;
+    uint4 wt[kRing];
+#pragma unroll
+    for (int j = 0; j < kRing; ++j)
+        if (b0 + j < b1) wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(b0 + j) * 1024);
+    BH_STAMP(1);
+
+    // ---- 3. prologue: [LayerNorm] -> fixed point -> digit planes in LDS --------------
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        if (t > 0) load_vec(p.x + (size_t)t * p.cols, xr);
+        if (p.ln_gamma) {
+            // LayerNorm without bias, WITH mean subtraction (T:89-97; candle LayerNorm
+            // slow path): (x - mean) / sqrt(mean((x - mean)^2) + eps) * gamma
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kNVMAX; ++i)
+                if (i < nv_iters) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+            const float mean = block_sum(s, scratch) / (float)p.cols;
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kNVMAX; ++i) {
+                if (i < nv_iters) {
+                    const bool in = tid + 256 * i < nvec;
+                    xr[i].x = in ? xr[i].x - mean : 0.0f;
+                    xr[i].y = in ? xr[i].y - mean : 0.0f;
+                    xr[i].z = in ? xr[i].z - mean : 0.0f;
+                    xr[i].w = in ? xr[i].w - mean : 0.0f;
+                    ss += (xr[i].x * xr[i].x + xr[i].y * xr[i].y) + (xr[i].z * xr[i].z + xr[i].w * xr[i].w);
+                }
+            }
+            const float denom = sqrtf(block_sum(ss, scratch) / (float)p.cols + p.ln_eps);
+#pragma unroll
+            for (int i = 0; i < kNVMAX; ++i) {  // padded lanes hold 0 and gamma 0
+                if (i >= nv_iters) continue;
+                xr[i].x = xr[i].x / denom * gr[i].x;
+                xr[i].y = xr[i].y / denom * gr[i].y;
+                xr[i].z = xr[i].z / denom * gr[i].z;
+                xr[i].w = xr[i].w / denom * gr[i].w;
+            }
+        }
+        float am = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kNVMAX; ++i)
+            if (i < nv_iters)
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[i].x), fabsf(xr[i].y))), fmaxf(fabsf(xr[i].z), fabsf(xr[i].w)));
+        am = block_max(am, scratch);
+        BH_STAMP(2);
+        // scale = 2^(29 - E), E = unbiased exponent of the row maximum (clamped so the
+        // scale stays a normal float); |x * scale| < 2^30
+        int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
+        be = be < 32 ? 32 : be;
+        const float sc = __uint_as_float((uint32_t)(283 - be) << 23);
+        if (tid == 0) inv_s[t] = __uint_as_float((uint32_t)(be - 29) << 23);
+#pragma unroll
+        for (int i = 0; i < kNVMAX; ++i) {
+            const int idx = tid + 256 * i;
+            if (i < (p.nblk * 64 + 255) >> 8 && idx < p.nblk * 64) {  // zero digits up to the padded K: tail codes add 0
+                uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                push_digits(xr[i].x, sc, 0, d0, d1, d2, d3);
+                push_digits(xr[i].y, sc, 1, d0, d1, d2, d3);
+                push_digits(xr[i].z, sc, 2, d0, d1, d2, d3);
+                push_digits(xr[i].w, sc, 3, d0, d1, d2, d3);
+                *reinterpret_cast<uint32_t *>(planes + (4 * t + 0) * ps + 4 * idx) = d0;
+                *reinterpret_cast<uint32_t *>(planes + (4 * t + 1) * ps + 4 * idx) = d1;
+                *reinterpret_cast<uint32_t *>(planes + (4 * t + 2) * ps + 4 * idx) = d2;
+                *reinterpret_cast<uint32_t *>(planes + (4 * t + 3) * ps + 4 * idx) = d3;
+            }
+        }
+    }
+    __syncthreads();
+    BH_STAMP(3);
+
+    // ---- 4. main loop: decode -> MFMA --------------------------------------------------
+    // B operand of lane (col c = r16, k-group g): 16 bytes of plane c (MT=1: c & 3).
+    const int plane = MT == 4 ? r16 : (r16 & 3);
+    const uint8_t *bbase = planes + plane * ps + 64 * g;
+    v4i acc = {0, 0, 0, 0};
+    float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = b0; c0 < b1; c0 += kRing) {
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) {
+            const int blk = c0 + j;
+            if (blk < b1) {
+                const uint32_t wd[4] = {wt[j].x, wt[j].y, wt[j].z, wt[j].w};
+                if (blk + kRing < b1)  // refill this ring slot right away
+                    wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(blk + kRing) * 1024);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const v4i a = decode16(wd[m], p.lut);
+                    const v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * blk + 16 * m);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+                }
+                if (p.wscale) {
+                    // one f32 weight scale per (row, 256-block): fold this block's exact
+                    // integer sums into f32 accumulators (rows 4g+j of the tile)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        int row = 16 * tile + 4 * g + jj;
+                        row = row < p.rows ? row : p.rows - 1;
+                        facc[jj] += (float)acc[jj] * p.wscale[(size_t)row * p.nblk + blk];
+                    }
+                    acc = (v4i){0, 0, 0, 0};
+                }
+            }
+        }
+    }
+    BH_STAMP(4);
+
+    // ---- 5. epilogue: digits -> f32, K-range reduction, store ---------------------------
+    const float cw = (MT == 4 || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) : 0.0f;
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = (p.wscale ? facc[j] : (float)acc[j]) * cw;
+        f[j] += __shfl_xor(f[j], 1, 64);
+        f[j] += __shfl_xor(f[j], 2, 64);
+    }
+    if ((r16 & 3) == 0 && (MT == 4 || r16 == 0)) {
+        const int t = MT == 4 ? (r16 >> 2) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(wave * MT + t) * 16 + 4 * g + j] = f[j];
+    }
+    __syncthreads();
+    if (!p.silu_mul) {
+        if (tid < tiles_per_wg * MT * 16) {
+            const int tl = tid / (MT * 16), t = (tid / 16) % MT, r = tid & 15;
+            const int row = 16 * (blockIdx.x * tiles_per_wg + tl) + r;
+            if (row < p.rows) {
+                float v = 0.0f;
+                for (int kp = 0; kp < p.ksplit; ++kp) v += part[((tl * p.ksplit + kp) * MT + t) * 16 + r];
+                v *= inv_s[t];
+                if (p.residual) v += p.residual[(size_t)t * p.rows + row];
+                p.y[(size_t)t * p.rows + row] = v;
+            }
+        }
+    } else {
+        // rows come in (gate tile, up tile) pairs; FeedForward::forward T:756-781:
+        // hidden = silu(gate) * up, silu(v) = v / (1 + exp(-v))
+        const int pairs_per_wg = tiles_per_wg / 2, half_rows = p.rows / 2;
+        if (tid < pairs_per_wg * MT * 16) {
+            const int pl = tid / (MT * 16), t = (tid / 16) % MT, r = tid & 15;
+            const int row = 16 * (blockIdx.x * pairs_per_wg + pl) + r;
+            if (row < half_rows) {
+                float gv = 0.0f, uv = 0.0f;
+                for (int kp = 0; kp < p.ksplit; ++kp) {
+                    gv += part[(((2 * pl) * p.ksplit + kp) * MT + t) * 16 + r];
+                    uv += part[(((2 * pl + 1) * p.ksplit + kp) * MT + t) * 16 + r];
+                }
+                gv *= inv_s[t];
+                uv *= inv_s[t];
+                p.y[(size_t)t * half_rows + row] = gv / (1.0f + expf(-gv)) * uv;
+            }
+        }
+    }
+    BH_STAMP(5);
+}
+
+unsigned long long *g_mfma_stamps = nullptr;  // set through bitnet_hip_debug_set_stamps (diagnostic build)
+
+bool mfma_supported(const Weights &w) {
+    if (w.cols == 0 || w.rows == 0) return false;
+    if (w.cols > (size_t)kNVMAX * 1024) return false;                    // prologue register budget
+    if (w.cols % 4 != 0) return false;                                   // float4 activation loads
+    if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;  // QK256-shaped rows
+    if (w.scales && w.block_size != 256) return false;                   // per-256-block f32 scales only
+    return true;
+}
+
+int mfma_pick_ksplit(size_t rows, size_t cols, bool paired) {
+    const size_t n_tiles = div_ceil(rows, 16), nblk = div_ceil(cols, 256);
+    // spread over the 256 CUs (4 waves each, several workgroups per CU) without
+    // leaving a wave fewer than ~2 tiles
+    int ks = 1;
+    const int ks_max = paired ? 2 : 4;
+    while (ks < ks_max && n_tiles * ks < 4 * 256 && (size_t)ks * 2 * 2 <= nblk) ks *= 2;
+    return ks;
+}
+
+hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu,
+                            hipStream_t stream) {
+    if (!w.tiles) return hipErrorInvalidValue;
+    MfmaArgs a;
+    a.tiles = w.tiles;
+    a.rows = (int)w.rows;
+    a.cols = (int)w.cols;
+    a.nblk = (int)div_ceil(w.cols, 256);
+    a.lut = w.lut;
+    a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul);
+    a.ln_gamma = fu.ln_gamma;
+    a.ln_eps = fu.ln_eps;
+    a.wscale = w.scales;
+    a.silu_mul = fu.silu_mul ? 1 : 0;
+    a.stamps = g_mfma_stamps;
+    const int tiles_per_wg = 4 / a.ksplit;
+    const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);
+    const size_t out_rows = fu.silu_mul ? w.rows / 2 : w.rows;
+    for (size_t m0 = 0; m0 < m;) {
+        const size_t left = m - m0;
+        a.x = x + m0 * w.cols;
+        a.y = y + m0 * out_rows;
+        a.residual = fu.residual ? fu.residual + m0 * w.rows : nullptr;
+        if (left >= 4) {
+            const size_t lds = (size_t)16 * (a.nblk * 256 + 16) + (8 + 4 * 4 * 16) * sizeof(float);
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemv_mfma<4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(k_gemv_mfma<4>, dim3(grid), dim3(256), lds, stream, a);
+            m0 += 4;
+        } else {
+            const size_t lds = (size_t)4 * (a.nblk * 256 + 16) + (8 + 4 * 16) * sizeof(float);
+            hipLaunchKernelGGL(k_gemv_mfma<1>, dim3(grid), dim3(256), lds, stream, a);
+            m0 += 1;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ---- tiled layout: [row tile][256-col block][lane][16 B], 2-bit fields transposed -----
+// dword in : field f = 4b + i (bits 2f..2f+1) holds element 4b + i  (byte b, slot i)
+// dword out: field 4b + i holds element 4i + b, so that (w >> 2i) & 0x03030303 puts
+//            elements 4i .. 4i+3 into bytes 0..3.
+__device__ __forceinline__ uint32_t transpose_fields(uint32_t w) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o |= ((w >> (2 * (4 * i + b))) & 3u) << (2 * (4 * b + i));
+    return o;
+}
+
+__global__ void k_retile(const uint8_t *__restrict__ codes, size_t row_stride, int rows, int nblk,
+                         uint8_t *__restrict__ tiles, size_t total16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte segment each
+    if (i >= total16) return;
+    const int lane = (int)(i & 63);
+    const size_t tb = i >> 6;
+    const int blk = (int)(tb % nblk);
+    const size_t tile = tb / nblk;
+    const int row = (int)(16 * tile + (lane & 15));
+    uint4 v = {0, 0, 0, 0};
+    if (row < rows) v = *reinterpret_cast<const uint4 *>(codes + (size_t)row * row_stride + 64 * blk + 16 * (lane >> 4));
+    v.x = transpose_fields(v.x);
+    v.y = transpose_fields(v.y);
+    v.z = transpose_fields(v.z);
+    v.w = transpose_fields(v.w);
+    *reinterpret_cast<uint4 *>(tiles + i * 16) = v;
+}
+
+hipError_t build_tiles(Weights &w, hipStream_t stream) {
+    if (w.tiles) return hipSuccess;
+    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
+    const size_t total16 = n_tiles * nblk * 64;
+    hipError_t e = hipMalloc((void **)&w.tiles, total16 * 16);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_retile, dim3((unsigned)div_ceil(total16, 256)), dim3(256), 0, stream, w.codes,
+                       w.row_stride_bytes, (int)w.rows, (int)nblk, w.tiles, total16);
+    w.n_row_tiles = n_tiles;
+    w.n_kblocks = nblk;
+    return hipGetLastError();
+}
+
+}  // namespace bitnet_hip

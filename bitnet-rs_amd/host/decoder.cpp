@@ -1,0 +1,401 @@
+// decoder.cpp -- see decoder.hpp.  Host orchestration only; every device operation is a
+// bitnet_hip_* call (include/bitnet_hip.h) or plain HIP memory / stream / graph plumbing.
+#include "decoder.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace bitnet_host {
+
+#define HCHK(expr)                                                                     \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            char _b[256];                                                              \
+            snprintf(_b, sizeof(_b), "HIP error %s at %s:%d (%s)", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
+            err_ = _b;                                                                 \
+            return BITNET_HIP_ERR_GPU;                                                 \
+        }                                                                              \
+    } while (0)
+#define BCHK(expr)                       \
+    do {                                 \
+        int _rc = (expr);                \
+        if (_rc != 0) return fail(#expr); \
+    } while (0)
+
+int Decoder::fail(const char *what) {
+    const char *e = bitnet_hip_get_last_error();
+    err_ = std::string(what) + ": " + (e ? e : "error");
+    return BITNET_HIP_ERR_EXECUTION;
+}
+
+template <class T>
+static hipError_t dalloc(T **p, size_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T) ? n * sizeof(T) : 1);
+}
+
+Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
+    if (bitnet_hip_init(-1) != 0) {
+        const char *e = bitnet_hip_get_last_error();
+        err_ = e ? e : "bitnet_hip_init failed";
+        return;
+    }
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        err_ = "hipStreamCreate failed";
+        return;
+    }
+    stream_ = s;
+    const size_t H = c_.hidden, D = c_.head_dim, half = D / 2;
+    bool ok = true;
+    ok &= dalloc(&x_, H) == hipSuccess && dalloc(&x2_, H) == hipSuccess;
+    ok &= dalloc(&qkv_, (size_t)(c_.n_heads + 2 * c_.n_kv_heads) * D) == hipSuccess;
+    ok &= dalloc(&att_, (size_t)c_.n_heads * D) == hipSuccess;
+    ok &= dalloc(&h_, (size_t)c_.ffn) == hipSuccess;
+    ok &= dalloc(&logits_, (size_t)c_.vocab) == hipSuccess;
+    ok &= hipMalloc(&scratch_, 8 * (size_t)logits_wgs_) == hipSuccess;
+    ok &= dalloc(&pos_, 1) == hipSuccess && dalloc(&n_forced_, 1) == hipSuccess && dalloc(&token_, 1) == hipSuccess;
+    ok &= dalloc(&history_, (size_t)c_.max_pos + 2) == hipSuccess;
+    ok &= dalloc(&rope_sin_, (size_t)c_.max_pos * half) == hipSuccess;
+    ok &= dalloc(&rope_cos_, (size_t)c_.max_pos * half) == hipSuccess;
+    for (auto &L : layers_) {
+        const size_t n = (size_t)c_.n_kv_heads * c_.max_pos * D;
+        ok &= dalloc(&L.kcache, n) == hipSuccess && dalloc(&L.vcache, n) == hipSuccess;
+        ok &= dalloc(&L.attn_norm, H) == hipSuccess && dalloc(&L.ffn_norm, H) == hipSuccess;
+    }
+    ok &= dalloc(&final_norm_, H) == hipSuccess;
+    if (!ok) {
+        err_ = "device allocation failed";
+        return;
+    }
+    // RoPE tables exactly as build_tables does (crates/bitnet-rope/src/lib.rs:59-93)
+    std::vector<float> sn((size_t)c_.max_pos * half), cs((size_t)c_.max_pos * half), inv(half);
+    for (size_t i = 0; i < half; ++i) inv[i] = 1.0f / powf(c_.rope_theta, (2.0f * (float)i) / (float)D);
+    for (int p = 0; p < c_.max_pos; ++p)
+        for (size_t i = 0; i < half; ++i) {
+            const float angle = (float)p * inv[i];
+            sn[(size_t)p * half + i] = sinf(angle);
+            cs[(size_t)p * half + i] = cosf(angle);
+        }
+    if (hipMemcpy(rope_sin_, sn.data(), sn.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(rope_cos_, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        err_ = "rope table upload failed";
+    reset();
+}
+
+Decoder::~Decoder() {
+    for (int i = 0; i < 2; ++i) {
+        if (graph_exec_[i]) hipGraphExecDestroy((hipGraphExec_t)graph_exec_[i]);
+        if (graph_[i]) hipGraphDestroy((hipGraph_t)graph_[i]);
+    }
+    for (auto &L : layers_) {
+        for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down})
+            if (h) bitnet_hip_weights_free(h);
+        for (float *p : {L.attn_norm, L.ffn_norm, L.kcache, L.vcache})
+            if (p) hipFree(p);
+    }
+    for (void *p : {(void *)embed_, (void *)final_norm_, (void *)rope_sin_, (void *)rope_cos_, (void *)x_, (void *)x2_,
+                    (void *)qkv_, (void *)att_, (void *)h_, (void *)logits_, scratch_, (void *)pos_, (void *)n_forced_,
+                    (void *)history_, (void *)token_})
+        if (p) hipFree(p);
+    if (stream_) hipStreamDestroy((hipStream_t)stream_);
+}
+
+int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
+    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    Layer &L = layers_[(size_t)layer];
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    auto stride = [](size_t cols) { return (cols + 255) / 256 * 64; };
+    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
+    bitnet_hip_weights_t q = 0, k = 0, v = 0, g = 0, u = 0;
+    BCHK(bitnet_hip_weights_upload_qk256(w.q, QD * stride(H), QD, H, stride(H), &q));
+    BCHK(bitnet_hip_weights_upload_qk256(w.k, KD * stride(H), KD, H, stride(H), &k));
+    BCHK(bitnet_hip_weights_upload_qk256(w.v, KD * stride(H), KD, H, stride(H), &v));
+    BCHK(bitnet_hip_weights_upload_qk256(w.o, H * stride(QD), H, QD, stride(QD), &L.o));
+    BCHK(bitnet_hip_weights_upload_qk256(w.gate, F * stride(H), F, H, stride(H), &g));
+    BCHK(bitnet_hip_weights_upload_qk256(w.up, F * stride(H), F, H, stride(H), &u));
+    BCHK(bitnet_hip_weights_upload_qk256(w.down, H * stride(F), H, F, stride(F), &L.down));
+    const bitnet_hip_weights_t qkv[3] = {q, k, v}, gu[2] = {g, u};
+    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
+    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
+    for (bitnet_hip_weights_t h : {q, k, v, g, u}) bitnet_hip_weights_free(h);
+    size_t b = 0;
+    for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down}) {
+        size_t ab = 0;
+        bitnet_hip_weights_info(h, nullptr, nullptr, &ab);
+        b += ab;
+    }
+    weight_bytes_ += b;
+    return 0;
+}
+
+int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
+    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    Layer &L = layers_[(size_t)layer];
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
+    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
+    bitnet_hip_weights_t h[7] = {0};
+    for (int i = 0; i < 7; ++i) {
+        const size_t pk = (k[i] + 3) / 4, nb = (k[i] + w.block_size - 1) / w.block_size;
+        BCHK(bitnet_hip_weights_upload_i2s(w.w[i], pk * n[i], w.scales[i], nb * n[i], n[i], k[i], w.block_size, &h[i]));
+    }
+    const bitnet_hip_weights_t qkv[3] = {h[0], h[1], h[2]}, gu[2] = {h[4], h[5]};
+    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
+    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
+    L.o = h[3];
+    L.down = h[6];
+    for (int i : {0, 1, 2, 4, 5}) bitnet_hip_weights_free(h[i]);
+    for (bitnet_hip_weights_t hh : {L.qkv, L.o, L.gateup, L.down}) {
+        size_t ab = 0;
+        bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
+        weight_bytes_ += ab;
+    }
+    return 0;
+}
+
+int Decoder::set_globals(const uint16_t *embed_f16, const float *final_norm) {
+    const size_t n = (size_t)c_.vocab * c_.hidden * 2;
+    if (!embed_) HCHK(hipMalloc(&embed_, n));
+    HCHK(hipMemcpy(embed_, embed_f16, n, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(final_norm_, final_norm, (size_t)c_.hidden * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Decoder::reset() {
+    host_forced_ = 0;
+    HCHK(hipMemset(pos_, 0, 4));
+    HCHK(hipMemset(n_forced_, 0, 4));
+    HCHK(hipMemset(history_, 0, ((size_t)c_.max_pos + 2) * 4));
+    return 0;
+}
+
+int Decoder::feed(const int32_t *tokens, int n) {
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    const int base = p > host_forced_ ? p : host_forced_;
+    if (base + n > c_.max_pos) {
+        err_ = "KV cache overflow";  // T:1190-1194
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    HCHK(hipMemcpy(history_ + base, tokens, (size_t)n * 4, hipMemcpyHostToDevice));
+    host_forced_ = base + n;
+    HCHK(hipMemcpy(n_forced_, &host_forced_, 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Decoder::position() {
+    int p = -1;
+    if (hipMemcpy(&p, pos_, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        err_ = "position readback failed";
+        return -1;
+    }
+    return p;
+}
+
+// One decode step = TransformerModel::forward (T:1557-1597) on one token + logits.
+int Decoder::step_launches(bool with_logits) {
+    void *s = stream_;
+    const size_t H = c_.hidden;
+    BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
+    for (auto &L : layers_) {
+        // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
+        BCHK(bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, s));
+        BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
+                                             (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, att_, s));
+        // o_proj + residual (T:542, T:1073)
+        BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
+        // post_attention_layernorm -> gate, up -> silu(gate)*up (T:1104, T:756-781)
+        BCHK(bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, s));
+        // down_proj + residual (T:789, T:1125)
+        BCHK(bitnet_hip_gemv_fused_dev(L.down, h_, x_, 1, nullptr, 0.f, x2_, 0, s));
+    }
+    if (with_logits) {
+        // final norm + tied logits + greedy token (T:1589, T:1599-1630, sampling.rs:189-202)
+        BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_,
+                                       (size_t)logits_wgs_, token_, pos_, history_, n_forced_, s));
+    } else {
+        BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+    }
+    return 0;
+}
+
+int Decoder::ensure_graph(bool with_logits) {
+    const int gi = with_logits ? 1 : 0;
+    if (graph_exec_[gi]) return 0;
+    hipStream_t s = (hipStream_t)stream_;
+    hipGraph_t g = nullptr;
+    HCHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    const int rc = step_launches(with_logits);
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc != 0) {
+        if (g) hipGraphDestroy(g);
+        return rc;
+    }
+    HCHK(e);
+    hipGraphExec_t ex = nullptr;
+    HCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    graph_[gi] = g;
+    graph_exec_[gi] = ex;
+    return 0;
+}
+
+int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    if (p + n > c_.max_pos - 1) {
+        err_ = "KV cache overflow";  // T:1190-1194
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    if (use_graph) {
+        // first call: run one eager step so lazily raised kernel attributes exist before capture
+        int rc = ensure_graph(with_logits);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    HCHK(hipEventCreate(&e0));
+    HCHK(hipEventCreate(&e1));
+    HCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < n; ++i) {
+        if (use_graph) {
+            HCHK(hipGraphLaunch((hipGraphExec_t)graph_exec_[with_logits ? 1 : 0], s));
+        } else {
+            int rc = step_launches(with_logits);
+            if (rc) return rc;
+        }
+    }
+    HCHK(hipEventRecord(e1, s));
+    HCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
+int Decoder::history(int32_t *out, int n) {
+    HCHK(hipMemcpy(out, history_, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int Decoder::last_logits(float *out) {
+    HCHK(hipMemcpy(out, logits_, (size_t)c_.vocab * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int Decoder::last_hidden(float *out) {
+    HCHK(hipMemcpy(out, x_, (size_t)c_.hidden * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int Decoder::layer_trace(float *) {
+    err_ = "layer trace is not kept";
+    return BITNET_HIP_ERR_UNSUPPORTED;
+}
+
+int Decoder::probe_gateup(int reps, float *us_per_launch, double *bytes_per_launch) {
+    hipStream_t s = (hipStream_t)stream_;
+    hipGraph_t g = nullptr;
+    HCHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    int rc = 0;
+    for (auto &L : layers_) {
+        rc = bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, stream_);
+        if (rc) break;
+    }
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) {
+        if (g) hipGraphDestroy(g);
+        return fail("probe_gateup launch");
+    }
+    HCHK(e);
+    hipGraphExec_t ex = nullptr;
+    HCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    HCHK(hipGraphLaunch(ex, s));  // warm
+    HCHK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    HCHK(hipEventCreate(&e0));
+    HCHK(hipEventCreate(&e1));
+    HCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) HCHK(hipGraphLaunch(ex, s));
+    HCHK(hipEventRecord(e1, s));
+    HCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipGraphExecDestroy(ex);
+    hipGraphDestroy(g);
+    if (us_per_launch) *us_per_launch = ms * 1e3f / (float)(reps * c_.n_layers);
+    if (bytes_per_launch) {
+        size_t ab = 0;
+        bitnet_hip_weights_info(layers_[0].gateup, nullptr, nullptr, &ab);
+        // + activation vector in, hidden vector out, gamma (cols*4 + 4*rows)
+        *bytes_per_launch = (double)ab + 4.0 * c_.hidden * 2 + 4.0 * c_.ffn;
+    }
+    return 0;
+}
+
+}  // namespace bitnet_host
+
+using bitnet_host::Decoder;
+
+extern "C" {
+void *bitnet_host_create(const bitnet_host_config *cfg) {
+    bitnet_host::Config c;
+    c.hidden = cfg->hidden;
+    c.n_layers = cfg->n_layers;
+    c.n_heads = cfg->n_heads;
+    c.n_kv_heads = cfg->n_kv_heads;
+    c.head_dim = cfg->head_dim;
+    c.ffn = cfg->ffn;
+    c.vocab = cfg->vocab;
+    c.max_pos = cfg->max_pos;
+    c.eps = cfg->eps;
+    c.rope_theta = cfg->rope_theta;
+    return new Decoder(c);
+}
+void bitnet_host_destroy(void *d) { delete static_cast<Decoder *>(d); }
+const char *bitnet_host_error(void *d) { return static_cast<Decoder *>(d)->error().c_str(); }
+int bitnet_host_set_layer_qk256(void *d, int layer, const float *attn_norm, const float *ffn_norm, const uint8_t *q,
+                                const uint8_t *k, const uint8_t *v, const uint8_t *o, const uint8_t *gate,
+                                const uint8_t *up, const uint8_t *down) {
+    bitnet_host::LayerWeightsQk256 w{attn_norm, ffn_norm, q, k, v, o, gate, up, down};
+    return static_cast<Decoder *>(d)->set_layer_qk256(layer, w);
+}
+int bitnet_host_set_layer_i2s(void *d, int layer, const float *attn_norm, const float *ffn_norm, const uint8_t *const *w7,
+                              const float *const *scales7, size_t block_size) {
+    bitnet_host::LayerWeightsI2s w;
+    w.attn_norm = attn_norm;
+    w.ffn_norm = ffn_norm;
+    for (int i = 0; i < 7; ++i) {
+        w.w[i] = w7[i];
+        w.scales[i] = scales7[i];
+    }
+    w.block_size = block_size;
+    return static_cast<Decoder *>(d)->set_layer_i2s(layer, w);
+}
+int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *final_norm) {
+    return static_cast<Decoder *>(d)->set_globals(embed_f16, final_norm);
+}
+int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
+int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
+int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
+    return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);
+}
+int bitnet_host_position(void *d) { return static_cast<Decoder *>(d)->position(); }
+int bitnet_host_history(void *d, int32_t *out, int n) { return static_cast<Decoder *>(d)->history(out, n); }
+int bitnet_host_last_logits(void *d, float *out) { return static_cast<Decoder *>(d)->last_logits(out); }
+int bitnet_host_last_hidden(void *d, float *out) { return static_cast<Decoder *>(d)->last_hidden(out); }
+int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch) {
+    return static_cast<Decoder *>(d)->probe_gateup(reps, us_per_launch, bytes_per_launch);
+}
+uint64_t bitnet_host_weight_bytes(void *d) { return static_cast<Decoder *>(d)->weight_bytes(); }
+}

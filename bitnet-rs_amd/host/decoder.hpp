@@ -1,0 +1,133 @@
+// decoder.hpp -- host-side decode loop over the C ABI (include/bitnet_hip.h).
+//
+// The reference keeps the autoregressive loop in host code (Rust) and calls kernels:
+//   TransformerModel::{embed, forward, logits}   crates/bitnet-transformer/src/lib.rs:1390, 1557, 1599
+//   TransformerBlock::forward                    :977-1134
+//   KVCache / LayerKVCache                       :1138-1256
+//   greedy loop                                  crates/bitnet-cli/src/main.rs:1282-1477
+//   parity entry points                          crates/bitnet-inference/src/parity.rs:30-111,157-223
+// Rust is not available in this build environment, so this is the same structure in
+// C++: it owns no arithmetic, only buffers, the launch order and a captured hipGraph
+// per decode step.  Everything it launches goes through bitnet_hip_* entry points.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bitnet_hip.h"
+
+namespace bitnet_host {
+
+// ModelConfig fields the path needs (crates/bitnet-common/src/config.rs:25-46; GGUF keys
+// crates/bitnet-models/src/gguf_simple.rs:646-777).
+struct Config {
+    int hidden = 2560, n_layers = 30, n_heads = 20, n_kv_heads = 5, head_dim = 128;
+    int ffn = 6912, vocab = 128256, max_pos = 4096;
+    float eps = 1e-5f;          // rms_norm_eps, default 1e-5 (T:957)
+    float rope_theta = 10000.f;  // DEFAULT_ROPE_BASE (crates/bitnet-rope/src/lib.rs:11)
+};
+
+// One layer's host-side weights in the reference's layouts.
+struct LayerWeightsQk256 {
+    const float *attn_norm, *ffn_norm;                       // [hidden]
+    const uint8_t *q, *k, *v, *o, *gate, *up, *down;         // QK256 bytes [out, ceil(in/256)*64]
+};
+// Ternary I2_S with f32 block scales (K/cpu/quantized_matmul.rs:47-56).
+struct LayerWeightsI2s {
+    const float *attn_norm, *ffn_norm;
+    const uint8_t *w[7];      // q,k,v,o,gate,up,down: [out, in/4]
+    const float *scales[7];   // [out, in/block]
+    size_t block_size;
+};
+
+class Decoder {
+  public:
+    explicit Decoder(const Config &cfg);
+    ~Decoder();
+    Decoder(const Decoder &) = delete;
+    Decoder &operator=(const Decoder &) = delete;
+
+    const Config &config() const { return c_; }
+    const std::string &error() const { return err_; }
+
+    // weights (uploaded once; fused q|k|v and interleaved gate/up handles are built here)
+    int set_layer_qk256(int layer, const LayerWeightsQk256 &w);
+    int set_layer_i2s(int layer, const LayerWeightsI2s &w);
+    int set_globals(const uint16_t *embed_f16, const float *final_norm);
+
+    // KVCache::clear (T:1251-1255) + token history
+    int reset();
+    // Put `n` forced tokens at positions [pos, pos+n) of the history (the prompt).
+    int feed(const int32_t *tokens, int n);
+    // Run `n` single-token steps (T:1482-1504 body each).  with_logits=false skips the
+    // logits GEMV for prompt positions nobody samples from.  Uses the captured graph
+    // when use_graph, else eager launches.  Synchronises the stream before returning.
+    int run(int n, bool with_logits, bool use_graph, float *elapsed_ms);
+    int position();                                  // tokens consumed so far
+    int history(int32_t *out, int n);                // first n tokens of the sequence
+    int last_logits(float *out);                     // [vocab], of the last step run with logits
+    int last_hidden(float *out);                     // residual stream after the last block (pre final norm)
+    int layer_trace(float *out);                     // eager debug: not kept (returns error)
+    // Dominant-kernel probe for bench.py: every layer's fused gate/up GEMV back to back in
+    // one graph, `reps` replays; returns the mean time per launch and the algorithmic
+    // bytes one launch reads.
+    int probe_gateup(int reps, float *us_per_launch, double *bytes_per_launch);
+    size_t weight_bytes() const { return weight_bytes_; }  // algorithmic bytes of all I2_S matrices
+    void *stream() const { return stream_; }
+
+  private:
+    int fail(const char *what);
+    int step_launches(bool with_logits);
+    int ensure_graph(bool with_logits);
+
+    Config c_;
+    std::string err_;
+    void *stream_ = nullptr;
+    struct Layer {
+        float *attn_norm = nullptr, *ffn_norm = nullptr;
+        bitnet_hip_weights_t qkv = 0, o = 0, gateup = 0, down = 0;
+        float *kcache = nullptr, *vcache = nullptr;
+    };
+    std::vector<Layer> layers_;
+    void *embed_ = nullptr;
+    float *final_norm_ = nullptr;
+    float *rope_sin_ = nullptr, *rope_cos_ = nullptr;
+    float *x_ = nullptr, *x2_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *h_ = nullptr, *logits_ = nullptr;
+    void *scratch_ = nullptr;
+    int32_t *pos_ = nullptr, *n_forced_ = nullptr, *history_ = nullptr, *token_ = nullptr;
+    int host_forced_ = 0;
+    size_t weight_bytes_ = 0;
+    void *graph_exec_[2] = {nullptr, nullptr};  // [with_logits]
+    void *graph_[2] = {nullptr, nullptr};
+    int logits_wgs_ = 1024;
+};
+
+}  // namespace bitnet_host
+
+// C shim for the Python tests / bench (ctypes).  Not part of the kernel boundary.
+extern "C" {
+typedef struct bitnet_host_config {
+    int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, ffn, vocab, max_pos;
+    float eps, rope_theta;
+} bitnet_host_config;
+void *bitnet_host_create(const bitnet_host_config *cfg);
+void bitnet_host_destroy(void *d);
+const char *bitnet_host_error(void *d);
+int bitnet_host_set_layer_qk256(void *d, int layer, const float *attn_norm, const float *ffn_norm,
+                                const uint8_t *q, const uint8_t *k, const uint8_t *v, const uint8_t *o,
+                                const uint8_t *gate, const uint8_t *up, const uint8_t *down);
+int bitnet_host_set_layer_i2s(void *d, int layer, const float *attn_norm, const float *ffn_norm,
+                              const uint8_t *const *w7, const float *const *scales7, size_t block_size);
+int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *final_norm);
+int bitnet_host_reset(void *d);
+int bitnet_host_feed(void *d, const int32_t *tokens, int n);
+int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
+int bitnet_host_position(void *d);
+int bitnet_host_history(void *d, int32_t *out, int n);
+int bitnet_host_last_logits(void *d, float *out);
+int bitnet_host_last_hidden(void *d, float *out);
+int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch);
+uint64_t bitnet_host_weight_bytes(void *d);
+}

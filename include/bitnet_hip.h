@@ -149,7 +149,8 @@ typedef uint64_t bitnet_hip_weights_t; /* opaque; 0 is never a valid handle */
 #define BITNET_HIP_KERNEL_AUTO 0
 #define BITNET_HIP_KERNEL_EXACT 1 /* one thread per output, reference summation order: bit-exact */
 #define BITNET_HIP_KERNEL_VALU 2  /* wave-per-row, f32 FMA, shuffle reduction */
-#define BITNET_HIP_KERNEL_MFMA 3  /* i8 MFMA on exact fixed-point activation digits */
+#define BITNET_HIP_KERNEL_MFMA 3  /* i8 MFMA on exact fixed-point activation digits, reference row-major codes */
+#define BITNET_HIP_KERNEL_MFMA_TILED 4 /* same, codes re-tiled at upload into 1-KiB lane-ordered tiles */
 int bitnet_hip_set_kernel(int kernel);
 int bitnet_hip_get_kernel(void);
 
@@ -176,6 +177,69 @@ int bitnet_hip_gemv_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev
  * batched; row-major, leading dimensions cols / rows) */
 int bitnet_hip_matmul_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                           void *stream);
+
+/* Several uploaded matrices with the same cols / code map / block size as ONE
+ * launch: rows concatenated (q|k|v share their input: T:288-290).  interleave16 != 0
+ * (exactly two matrices of equal rows % 16 == 0) alternates 16-row tiles a0,b0,a1,b1..
+ * so a (gate, up) pair meets in one workgroup (BITNET_HIP_FUSE_SILU_MUL). */
+int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts, int interleave16,
+                              bitnet_hip_weights_t *out);
+
+/* GEMV with the neighbouring decode-step work fused in (MFMA kernel):
+ *   ln_gamma != NULL : x <- LayerNorm(x) first -- no bias, WITH mean subtraction,
+ *                      (x-mean)/sqrt(mean((x-mean)^2)+eps)*gamma  (T:67-100, T:1015, T:1104)
+ *   residual != NULL : y = residual + W x                        (T:1073, T:1125)
+ *   BITNET_HIP_FUSE_SILU_MUL (handle from concat(..., interleave16=1)):
+ *                      y[r] = silu(gate[r]) * up[r], y has rows/2   (T:756-781) */
+#define BITNET_HIP_FUSE_SILU_MUL 1
+int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
+                              const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
+                              int flags, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* 3. decode-step operators (device pointers; K/rocm/rmsnorm.rs, attention.rs) */
+/* ------------------------------------------------------------------------- */
+
+/* rmsnorm_hip(input, gamma, output, num_rows, &HipRmsNormConfig{hidden_dim, eps})
+ * K/rocm/rmsnorm.rs:50-60, host pointers: out = x / sqrt(mean(x^2)+eps) * gamma. */
+int bitnet_hip_rmsnorm(const float *input, size_t in_len, const float *gamma, size_t gamma_len,
+                       float *output, size_t out_len, size_t num_rows, size_t hidden_dim, float eps);
+/* Device rows: rms != 0 -> RMSNorm (above); rms == 0 -> the LayerNorm the transformer
+ * actually uses (layer_norm_with_optional_bias T:67-100: no bias, mean subtracted). */
+int bitnet_hip_norm_rows_dev(const float *x_dev, const float *gamma_dev, float *out_dev, size_t rows,
+                             size_t hidden, float eps, int rms, void *stream);
+/* TransformerModel::embed (T:1390-1426), row gather from the f16 table [vocab, hidden];
+ * tokens_dev: int32[]; reads tokens_dev[*offset_dev + i], i < n (offset_dev NULL = 0), so a
+ * captured graph can walk a token history by position. */
+int bitnet_hip_embed_f16_dev(const void *table_f16_dev, const int32_t *tokens_dev,
+                             const int32_t *offset_dev, size_t n, size_t hidden, size_t vocab,
+                             float *out_dev, void *stream);
+/* *pos_dev += 1 (prompt positions whose logits nobody reads). */
+int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream);
+/* One new token through MultiHeadAttention::forward's core (T:373-540): RoPE on q,k with
+ * the split-half layout (T:134-163) at position *pos_dev, append k,v to the f32 cache
+ * [n_kv][max_pos][head_dim] (T:1171-1202), GQA softmax attention over pos+1 keys.
+ * qkv_dev: [n_heads*D | n_kv*D | n_kv*D] raw projections; out_dev: [n_heads*D].
+ * rope_sin/cos_dev: [max_pos, D/2] (crates/bitnet-rope/src/lib.rs:59-93). */
+int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_dev,
+                                    const float *rope_cos_dev, float *kcache_dev, float *vcache_dev,
+                                    size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                    const int32_t *pos_dev, float *out_dev, void *stream);
+/* TransformerModel::logits, tied embeddings (T:1599-1630): logits = LN(x) . E^T, E the f16
+ * table [vocab, hidden], f32 accumulate; gamma_dev == NULL skips the final norm (T:1589).
+ * scratch_dev: >= 8 * n_workgroups bytes (argmax partials); token_dev (nullable) receives
+ * the greedy token (argmax, lowest index on ties, NaN -> -inf:
+ * crates/bitnet-cli/src/sampling.rs:45-49,189-202); with p = *pos_dev (nullable):
+ * history_dev[p+1] = token unless p+1 < *n_forced_dev (a prompt token already sits there),
+ * then *pos_dev = p+1. */
+int bitnet_hip_logits_f16_dev(const void *table_f16_dev, const float *x_dev, const float *gamma_dev,
+                              float eps, size_t hidden, size_t vocab, float *logits_dev,
+                              void *scratch_dev, size_t n_workgroups, int32_t *token_dev,
+                              int32_t *pos_dev, int32_t *history_dev, const int32_t *n_forced_dev,
+                              void *stream);
+/* argmax over a device vector with the same tie/NaN rules; scratch as above. */
+int bitnet_hip_argmax_dev(const float *v_dev, size_t n, void *scratch_dev, size_t n_workgroups,
+                          int32_t *token_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,44 @@ void bo_unpack_2bit_values(const uint8_t *packed, size_t packed_len, size_t outp
 void bo_dequantize_blocks(const int8_t *q, size_t n, const float *scales, size_t block_size,
                           float *out);
 
+/* ---- decode step around the GEMVs : transformer_oracle.c ---------------- */
+
+typedef struct bo_model_cfg {
+    int hidden, n_layers, n_heads, n_kv_heads, head_dim, ffn, vocab, max_pos;
+    float eps, rope_theta;
+} bo_model_cfg;
+
+/* crates/bitnet-rope/src/lib.rs:59-93 */
+void bo_rope_build_tables(int dim, int max_seq_len, float base, float *sin_out, float *cos_out);
+/* T:134-163 (split halves), one head vector */
+void bo_rope_apply(float *x, int dim, const float *sin_row, const float *cos_row);
+/* T:67-100: LayerNorm without bias, with mean subtraction */
+void bo_layernorm(const float *x, const float *w, float eps, int n, float *out);
+/* K/rocm/rmsnorm.rs:1-12 formula */
+void bo_rmsnorm(const float *x, const float *w, float eps, int n, float *out);
+float bo_silu(float v);
+/* crates/bitnet-cli/src/sampling.rs:189-202 */
+int bo_argmax(const float *logits, size_t n);
+/* T:398-543 for one query row against t_k cached positions */
+void bo_attention_decode(const float *q, const float *kc, const float *vc, int n_heads,
+                         int n_kv_heads, int dim, int max_pos, int t_k, float *out);
+
+/* Model = pointers to caller-owned arrays (nothing is copied). */
+void *bo_model_create(const bo_model_cfg *cfg, int n_threads);
+void bo_model_destroy(void *m);
+int bo_model_set_layer(void *m, int layer, const float *attn_norm, const float *ffn_norm,
+                       const uint8_t *q, const uint8_t *k, const uint8_t *v, const uint8_t *o,
+                       const uint8_t *gate, const uint8_t *up, const uint8_t *down);
+void bo_model_set_globals(void *m, const uint16_t *embed_f16, const float *final_norm);
+void *bo_kv_create(void *m);
+void bo_kv_destroy(void *kv);
+void bo_kv_reset(void *kv);
+int bo_kv_len(void *kv);
+/* T:1599-1630 */
+void bo_logits(void *m, const float *hidden, float *logits);
+/* one token: T:1482-1504 body (embed -> 30 blocks -> final norm -> logits) */
+int bo_model_step(void *m, void *kv, int token, float *hidden_out, float *logits_out, float *trace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -313,3 +313,101 @@ def ref_dequantize_row_iq2_s(d_bits: int, qs64) -> np.ndarray:
     y = np.zeros(256, np.float32)
     R.dequantize_row_iq2_s(C.byref(blk), y.ctypes.data_as(_f32p), 256)
     return y
+
+
+# ---- decode step (transformer_oracle.c) ---------------------------------------
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "ffn", "vocab", "max_pos")] + [
+        ("eps", C.c_float),
+        ("rope_theta", C.c_float),
+    ]
+
+
+class OracleModel:
+    """CPU restatement of the reference's per-token decode step (T:1482-1504)."""
+
+    def __init__(self, cfg, layers: list, glob: dict, n_threads: int = 1):
+        L = lib()
+        L.bo_model_create.restype = C.c_void_p
+        L.bo_model_create.argtypes = [C.POINTER(ModelCfg), C.c_int]
+        L.bo_model_destroy.argtypes = [C.c_void_p]
+        L.bo_model_set_layer.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p] + [_u8p] * 7
+        L.bo_model_set_globals.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), _f32p]
+        L.bo_kv_create.restype = C.c_void_p
+        L.bo_kv_create.argtypes = [C.c_void_p]
+        L.bo_kv_destroy.argtypes = [C.c_void_p]
+        L.bo_kv_reset.argtypes = [C.c_void_p]
+        L.bo_model_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _f32p, _f32p, _f32p]
+        L.bo_argmax.argtypes = [_f32p, _sz]
+        self.cfg = cfg
+        mc = ModelCfg(**{k: (float(v) if k in ("eps", "rope_theta") else int(v)) for k, v in cfg.asdict().items()})
+        self.m = L.bo_model_create(C.byref(mc), n_threads)
+        self._keep = []
+        for i, w in enumerate(layers):
+            a = [np.ascontiguousarray(w["attn_norm"], np.float32), np.ascontiguousarray(w["ffn_norm"], np.float32)]
+            a += [np.ascontiguousarray(w[k], np.uint8) for k in ("q", "k", "v", "o", "gate", "up", "down")]
+            self._keep.append(a)
+            rc = L.bo_model_set_layer(self.m, i, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), *[x.ctypes.data_as(_u8p) for x in a[2:]])
+            assert rc == 0
+        e, f = np.ascontiguousarray(glob["embed_f16"], np.uint16), np.ascontiguousarray(glob["final_norm"], np.float32)
+        self._keep.append((e, f))
+        L.bo_model_set_globals(self.m, e.ctypes.data_as(C.POINTER(C.c_uint16)), f.ctypes.data_as(_f32p))
+        self.kv = L.bo_kv_create(self.m)
+
+    def reset(self):
+        lib().bo_kv_reset(self.kv)
+
+    def step(self, token: int, want_logits: bool = True, want_trace: bool = False):
+        """Returns (final-normed hidden, logits or None, per-layer residual trace or None)."""
+        hid = np.zeros(self.cfg.hidden, np.float32)
+        logits = np.zeros(self.cfg.vocab, np.float32) if want_logits else None
+        trace = np.zeros((self.cfg.n_layers, self.cfg.hidden), np.float32) if want_trace else None
+        rc = lib().bo_model_step(self.m, self.kv, int(token), hid.ctypes.data_as(_f32p),
+                                 logits.ctypes.data_as(_f32p) if want_logits else None,
+                                 trace.ctypes.data_as(_f32p) if want_trace else None)
+        if rc != 0:
+            raise OracleError(f"bo_model_step rc={rc}")
+        return hid, logits, trace
+
+    def close(self):
+        if self.m:
+            lib().bo_kv_destroy(self.kv)
+            lib().bo_model_destroy(self.m)
+            self.m = None
+
+
+def argmax(logits) -> int:
+    a, ap = _f32(logits)
+    lib().bo_argmax.argtypes = [_f32p, _sz]
+    return int(lib().bo_argmax(ap, a.size))
+
+
+def layernorm(x, w, eps) -> np.ndarray:
+    xa, xp = _f32(x)
+    wa, wp = _f32(w)
+    out = np.zeros(xa.size, np.float32)
+    L = lib()
+    L.bo_layernorm.argtypes = [_f32p, _f32p, C.c_float, C.c_int, _f32p]
+    L.bo_layernorm(xp, wp, eps, xa.size, out.ctypes.data_as(_f32p))
+    return out
+
+
+def rmsnorm(x, w, eps) -> np.ndarray:
+    xa, xp = _f32(x)
+    wa, wp = _f32(w)
+    out = np.zeros(xa.size, np.float32)
+    L = lib()
+    L.bo_rmsnorm.argtypes = [_f32p, _f32p, C.c_float, C.c_int, _f32p]
+    L.bo_rmsnorm(xp, wp, eps, xa.size, out.ctypes.data_as(_f32p))
+    return out
+
+
+def rope_tables(dim: int, max_seq_len: int, base: float):
+    sin = np.zeros((max_seq_len, dim // 2), np.float32)
+    cos = np.zeros((max_seq_len, dim // 2), np.float32)
+    L = lib()
+    L.bo_rope_build_tables.argtypes = [C.c_int, C.c_int, C.c_float, _f32p, _f32p]
+    L.bo_rope_build_tables(dim, max_seq_len, base, sin.ctypes.data_as(_f32p), cos.ctypes.data_as(_f32p))
+    return sin, cos

@@ -37,11 +37,12 @@ def qk256_inputs(rows, cols, seed):
     return qs, x, stride
 
 
-KERNELS = ["exact", "valu", "auto"]
+KERNELS = ["exact", "valu", "mfma", "mfma_tiled", "auto"]
+STREAMING = ["valu", "mfma", "mfma_tiled", "auto"]
 
 
 def _set(hip, pkg, name):
-    hip.set_kernel({"auto": pkg.KERNEL_AUTO, "exact": pkg.KERNEL_EXACT, "valu": pkg.KERNEL_VALU, "mfma": pkg.KERNEL_MFMA}[name])
+    hip.set_kernel({"auto": pkg.KERNEL_AUTO, "exact": pkg.KERNEL_EXACT, "valu": pkg.KERNEL_VALU, "mfma": pkg.KERNEL_MFMA, "mfma_tiled": pkg.KERNEL_MFMA_TILED}[name])
 
 
 @pytest.fixture(autouse=True)
@@ -160,7 +161,7 @@ def test_gemv_qk256_exact_kernel_bit_identical(hip, pkg, oracle, rows, cols):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("kernel", ["valu", "auto"])
+@pytest.mark.parametrize("kernel", STREAMING)
 @pytest.mark.parametrize("rows,cols", [(4, 256), (3, 300), (7, 263), (16, 512), (8, 1024), (33, 2048), (5, 4096)] + MODEL_SHAPES)
 def test_gemv_qk256_streaming_parity(hip, pkg, oracle, kernel, rows, cols):
     qs, x, stride = qk256_inputs(rows, cols, 42)
@@ -200,7 +201,7 @@ def test_i2s_ternary_matmul_parity(hip, pkg, oracle, n, k, bs, m):
     want = oracle.i2s_matmul(act, packed, scales, m, n, k, bs)
     hip.set_kernel(pkg.KERNEL_EXACT)
     assert np.array_equal(hip.i2s_matmul_f32(act, packed, scales, m, n, k, bs), want)
-    for kernel in ("valu", "auto"):
+    for kernel in STREAMING:
         _set(hip, pkg, kernel)
         got = hip.i2s_matmul_f32(act, packed, scales, m, n, k, bs)
         assert np.all(approx_eq_with_len(got, want, k)), kernel
@@ -312,7 +313,7 @@ def test_full_size_linearity_and_row_independence(hip, pkg):
     vector returns the row sums of the decoded weights (integer-exact)."""
     import torch
 
-    for kernel in ("valu", "auto"):
+    for kernel in STREAMING:
         _set(hip, pkg, kernel)
         for rows, cols in MODEL_SHAPES:
             qs, _, stride = qk256_inputs(rows, cols, 100 + rows % 7)

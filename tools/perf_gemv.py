@@ -30,10 +30,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--kernels", default="valu")
     ap.add_argument("--fmt", default="qk256")
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     hip = pkg.load()
     hip.init(0)
-    kid = {"exact": pkg.KERNEL_EXACT, "valu": pkg.KERNEL_VALU, "mfma": pkg.KERNEL_MFMA, "auto": pkg.KERNEL_AUTO}
+    kid = {"exact": pkg.KERNEL_EXACT, "valu": pkg.KERNEL_VALU, "mfma": pkg.KERNEL_MFMA, "mfma_tiled": pkg.KERNEL_MFMA_TILED, "auto": pkg.KERNEL_AUTO}
     rng = np.random.default_rng(42)
     for name, (rows, cols) in SHAPES.items():
         handles = []
@@ -58,12 +59,27 @@ def main():
                 hip.gemv_dev(h, x, y, stream)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                for h in handles:
-                    hip.gemv_dev(h, x, y, stream)
-            e1.record()
-            torch.cuda.synchronize()
+            if args.graph:
+                # one graph = one pass over every layer's matrix: no host launch cost
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    cs = torch.cuda.current_stream().cuda_stream
+                    for h in handles:
+                        hip.gemv_dev(h, x, y, cs)
+                gr.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(args.iters):
+                    gr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+            else:
+                e0.record()
+                for _ in range(args.iters):
+                    for h in handles:
+                        hip.gemv_dev(h, x, y, stream)
+                e1.record()
+                torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (args.iters * len(handles))
             gbs = abytes / us / 1e3
             print(f"{args.fmt:6s} {kname:6s} {name:8s} {rows:5d}x{cols:5d}  {us:8.2f} us/launch  {gbs:8.1f} GB/s  {100 * gbs * 1e9 / PEAK:5.1f}% of 8TB/s", flush=True)
