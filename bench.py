@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s + I2_S matmul HBM GB/s (% roofline) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): bitnet-b1.58-2B-4T shapes, I2_S ternary weights
+with 32-element block scales (BitNet32), batch-1 greedy decode after a 128-token prompt,
+synthetic weights (seeded random codes of that architecture) and synthetic prompt ids.
+A step = ONE decode token through the whole step: embedding gather, 30 x (LayerNorm ->
+q|k|v GEMV -> RoPE + KV append + GQA attention -> o GEMV + residual -> LayerNorm ->
+gate|up GEMV -> silu*mul -> down GEMV + residual), final LayerNorm, tied-embedding logits
+over 128256 rows, greedy argmax -- every kernel inside the timed region, weights and KV
+cache resident in HBM, the next token fed back on the device.
+
+Batch-1 decode does not shard: with N > 1 each rank drives an independent
+replica ("replicas only", weak scaling); value = N * K / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `--workload c3` switches to the QK256 no-scale format
+(BASELINE.json configs[2], the reference's live decode path).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+PROMPT_LEN = 128
+
+
+def build_model(pkg, synth, workload: str, layers_override: int | None):
+    cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
+    if layers_override:
+        cfg.n_layers = layers_override
+    cfg.max_pos = 1024  # 128-token prompt + decode steps; KV cache sized for it
+    dec = pkg.HostDecoder(cfg)
+    keep = None
+    for l in range(cfg.n_layers):
+        if workload == "c3":
+            w = synth.make_layer(cfg, l, fmt="qk256")
+            dec.set_layer_qk256(l, w)
+        else:
+            w = synth.make_layer(cfg, l, fmt="i2s", block=32)
+            dec.set_layer_i2s(l, w, 32)
+        if l == 0:
+            keep = w
+    dec.set_globals(synth.make_globals(cfg))
+    return cfg, dec, keep
+
+
+def cpu_baseline(cfg, synth):
+    """The reference's live CPU decode path (QK256 AVX2 GEMV per projection,
+    Q/i2s_qk256_avx2.rs:254-295, single-threaded like the reference's row loop
+    Q/i2s_qk256.rs:313-318), restated in oracle/ and timed on this host.
+    Bounded sample: one layer's 7 GEMVs (1 warm-up + 3 timed, median) scaled by 30
+    layers, plus the tied-embedding logits GEMV timed once."""
+    from oracle import oracle as orc
+
+    orc.build()
+    w = synth.make_layer(cfg, 0, fmt="qk256")
+    shapes = cfg.shapes()
+    rng = np.random.default_rng(43)
+    xs = {c: rng.uniform(-10, 10, c).astype(np.float32) for c in {s[1] for s in shapes.values()}}
+    impl = "avx2" if orc.have_avx2() else "scalar"
+
+    def one_layer():
+        t0 = time.perf_counter()
+        for name, (rows, cols) in shapes.items():
+            orc.gemv_qk256(w[name], xs[cols], rows, cols, cols // 256 * 64, impl=impl)
+        return time.perf_counter() - t0
+
+    one_layer()
+    t_layer = float(np.median([one_layer() for _ in range(3)]))
+    # logits: f32 accumulate over the f16 table, one thread; timed on 1/16 of the rows
+    rows = cfg.vocab // 16
+    table = np.random.default_rng(7).standard_normal((rows, cfg.hidden)).astype(np.float16).astype(np.float32)
+    h = xs[cfg.hidden]
+    t0 = time.perf_counter()
+    _ = table @ h
+    t_logits = (time.perf_counter() - t0) * 16
+    tok_s = 1.0 / (cfg.n_layers * t_layer + t_logits)
+    return {
+        "value": round(tok_s, 4),
+        "unit": "tokens/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/ restatement of gemv_qk256_{impl} on 1 layer (7 GEMVs, 17.4 MB codes), median of 3 after 1 warm-up = "
+        f"{t_layer * 1e3:.1f} ms, x{cfg.n_layers} layers + logits GEMV ({t_logits * 1e3:.0f} ms, numpy f32 on 1/16 of the vocab x16); "
+        "reference published 0.5126 tok/s on a 9950X3D (docs/baselines/perf/phase2_timing_i2s.md)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    pkg = importlib.import_module("bitnet-rs_amd")
+    synth = importlib.import_module("bitnet-rs_amd.synth")
+    if not os.path.exists(pkg.LIB_PATH) or not os.path.exists(pkg.HOST_LIB_PATH):
+        pkg.build()
+    hip = pkg.load()
+    hip.init(local_rank)
+
+    cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers)
+    assert PROMPT_LEN + args.warmup + args.steps + 2 < cfg.max_pos
+    prompt = synth.prompt(PROMPT_LEN, cfg.vocab)
+    dec.reset()
+    dec.feed(prompt)
+    use_graph = not args.eager
+    dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
+    dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
+    dec.run(args.warmup, with_logits=True, use_graph=use_graph)      # W untimed warm-up steps
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = dec.run(args.steps, with_logits=True, use_graph=use_graph)  # exactly K timed steps (stream-synchronised inside)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = n_gpus * args.steps / elapsed
+    tokens = dec.history(PROMPT_LEN + 1 + args.warmup + args.steps)
+
+    # dominant kernel: the fused gate|up GEMV (largest byte stream of a layer).  Every
+    # layer's instance back to back (distinct weights: 30 x 13-17 MB > L2, cycling the
+    # whole model through HBM), HIP events on the launch stream, mean per launch.
+    us, abytes = dec.probe_gateup(50)
+    achieved = abytes / us / 1e3  # GB/s
+    roofline = {
+        "bound": "hbm",
+        "kernel": "k_gemv_mfma (fused LayerNorm -> gate|up GEMV -> silu*mul)" if True else "",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "bytes_per_launch": int(abytes),
+        "us_per_launch": round(us, 3),
+    }
+    # whole-step view of the same metric: all I2_S matrices of one token / step time
+    wb = dec.weight_bytes()
+    i2s_gbs = wb / (elapsed / args.steps) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/sec + I2_S matmul HBM GB/s (% roofline), bitnet-b1.58-2B-4T",
+            "value": round(value, 2),
+            "unit": "tokens/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i8 MFMA on exact 30-bit fixed-point activations, f32 accumulate / f32 elsewhere (f16 embedding table)",
+            "data": "synthetic",
+            "config": {
+                "workload": "bitnet-b1.58-2B-4T I2_S BitNet32 (ternary, 32-elem block scales), 1xMI355X, batch=1 decode, 128-token prompt"
+                if args.workload == "c2"
+                else "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt",
+                "layers": cfg.n_layers,
+                "prompt_len": PROMPT_LEN,
+                "kv_len_during_timing": [PROMPT_LEN + 1 + args.warmup, PROMPT_LEN + 1 + args.warmup + args.steps],
+                "parallelism": f"replicas x{n_gpus}" if n_gpus > 1 else "single GPU",
+                "launch": "hipGraph replay per token" if use_graph else "eager",
+            },
+            "i2s_matmul_gbs_whole_step": round(i2s_gbs, 1),
+            "i2s_matmul_frac_of_hbm_peak_whole_step": round(i2s_gbs / HBM_PEAK_GBS, 4),
+            "i2s_weight_bytes_per_token": int(wb),
+            "event_ms_per_step": round(ev_ms / args.steps, 4),
+            "roofline": roofline,
+            "last_tokens": [int(t) for t in tokens[-4:]],
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, synth)
+        print(json.dumps(out), flush=True)
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

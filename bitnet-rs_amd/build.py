@@ -105,7 +105,7 @@ def _build_host(force: bool, verbose: bool, kernel_lib: str) -> str:
     deps += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)] + [kernel_lib]
     if force or _stale(HOST_LIB_PATH, deps):
         cmd = [
-            "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__",
+            "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-int-in-bool-context", "-D__HIP_PLATFORM_AMD__",
             f"-I{INCLUDE}", f"-I{HOST_DIR}", "-I/opt/rocm/include", *srcs, "-o", HOST_LIB_PATH,
             f"-L{HERE}", "-lbitnet_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
         ]

@@ -28,6 +28,7 @@ void free_weights(Weights *w) {
     if (w->codes) (void)hipFree(w->codes);
     if (w->scales) (void)hipFree(w->scales);
     if (w->tiles) (void)hipFree(w->tiles);
+    if (w->scale_tiles) (void)hipFree(w->scale_tiles);
     delete w;
 }
 
@@ -363,6 +364,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->codes = nullptr;
     f->scales = nullptr;
     f->tiles = nullptr;
+    f->scale_tiles = nullptr;
     f->rows = rows;
     f->paired = interleave16 != 0;
     f->algorithmic_bytes = 0;
@@ -457,8 +459,9 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_dev");
     if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
-    if (head_dim == 0 || head_dim > 128 || 256 % head_dim != 0 || head_dim % 8 != 0)
-        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu unsupported (32/64/128)", head_dim);
+    if (head_dim != 128 || n_heads / n_kv_heads > 4)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
+                         head_dim, n_heads / n_kv_heads);
     BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
                                   (int)max_pos, pos_dev, out, (hipStream_t)stream));
     return BITNET_HIP_OK;

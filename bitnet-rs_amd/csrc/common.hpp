@@ -63,6 +63,7 @@ struct Weights {
     // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
     // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
     uint8_t *tiles = nullptr;
+    float *scale_tiles = nullptr;  // 32-block scales in tile order (kernels_mfma.hip k_retile_scales)
     size_t n_row_tiles = 0, n_kblocks = 0;
     bool paired = false;  // rows are interleaved (gate tile, up tile) pairs (weights_concat interleave16)
 };

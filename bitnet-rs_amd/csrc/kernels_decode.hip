@@ -96,9 +96,14 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
 }
 
 // ---- one-token attention: RoPE (T:134-163) + KV append (T:1171-1202) + GQA softmax
-//      attention (T:410-533).  One workgroup per query head. -------------------------------
+//      attention (T:410-533).  One workgroup per KV head serves its whole query group, so
+//      each K / V element is read once per group. -----------------------------------------
 // qkv: [n_heads*D | n_kv*D | n_kv*D] raw projections of the new token.
-// kcache/vcache: [n_kv][max_pos][D] f32 for this layer.  *pos_ptr = number of cached tokens.
+// Cache layout (private to this library): K is kept TRANSPOSED, kcache[n_kv][D][max_pos],
+// so the score pass reads positions contiguously (thread = position, no shuffles);
+// vcache[n_kv][max_pos][D] so the P.V pass reads dims contiguously.  *pos_ptr = cached tokens.
+constexpr int kMaxGroup = 4;
+
 __global__ __launch_bounds__(256) void k_attn_decode(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
                                                      const float *__restrict__ rope_cos, float *__restrict__ kcache,
                                                      float *__restrict__ vcache, int n_heads, int n_kv, int D,
@@ -107,83 +112,127 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float *__restrict__ q
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int pos = *pos_ptr;
     const int t_k = pos + 1;
-    const int h = blockIdx.x, group = n_heads / n_kv, kvh = h / group, half = D >> 1;
-    float *qs = sm;            // [D] rotated query
-    float *kn = qs + D;        // [D] rotated new key
-    float *vn = kn + D;        // [D] new value
-    float *slot = vn + D;      // [4]
-    float *red = slot + 4;     // [2*D] halves of P.V
-    float *sc = red + 2 * D;   // [t_k] scores -> probabilities
-    const int tid = threadIdx.x;
-    const float *q_raw = qkv + (size_t)h * D;
-    const float *k_raw = qkv + (size_t)n_heads * D + (size_t)kvh * D;
-    const float *v_raw = qkv + (size_t)(n_heads + n_kv) * D + (size_t)kvh * D;
+    const int kvh = blockIdx.x, group = n_heads / n_kv, half = D >> 1;
+    float *qs = sm;                     // [kMaxGroup][D] rotated queries of this group
+    float *kn = qs + kMaxGroup * D;     // [D] rotated new key
+    float *vn = kn + D;                 // [D] new value
+    float *red = vn + D;                // [4 waves][kMaxGroup] reduction scratch
+    float *sc = red + 4 * kMaxGroup;    // [kMaxGroup][max_pos] scores -> probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
-    if (tid < half) {
-        const float s = sr[tid], c = cr[tid];
-        const float q0 = q_raw[tid], q1 = q_raw[half + tid];
-        qs[tid] = q0 * c - q1 * s;
-        qs[half + tid] = q0 * s + q1 * c;
-        const float k0 = k_raw[tid], k1 = k_raw[half + tid];
+    for (int i = tid; i < group * half; i += 256) {  // RoPE on the group's queries
+        const int g = i / half, j = i % half;
+        const float *q_raw = qkv + (size_t)(kvh * group + g) * D;
+        const float s = sr[j], c = cr[j], q0 = q_raw[j], q1 = q_raw[half + j];
+        qs[g * D + j] = q0 * c - q1 * s;
+        qs[g * D + half + j] = q0 * s + q1 * c;
+    }
+    if (tid < half) {  // RoPE on the new key
+        const float *k_raw = qkv + (size_t)n_heads * D + (size_t)kvh * D;
+        const float s = sr[tid], c = cr[tid], k0 = k_raw[tid], k1 = k_raw[half + tid];
         kn[tid] = k0 * c - k1 * s;
         kn[half + tid] = k0 * s + k1 * c;
+    } else if (tid >= 128 && tid < 128 + D) {
+        vn[tid - 128] = qkv[(size_t)(n_heads + n_kv) * D + (size_t)kvh * D + (tid - 128)];
     }
-    if (tid < D) vn[tid] = v_raw[tid];
     __syncthreads();
-    float *kc = kcache + (size_t)kvh * max_pos * D, *vc = vcache + (size_t)kvh * max_pos * D;
-    if (h % group == 0 && tid < D) {  // one workgroup per KV head appends
-        kc[(size_t)pos * D + tid] = kn[tid];
+    float *kt = kcache + (size_t)kvh * D * max_pos;  // [D][max_pos]
+    float *vc = vcache + (size_t)kvh * max_pos * D;  // [max_pos][D]
+    if (tid < D) {
+        kt[(size_t)tid * max_pos + pos] = kn[tid];
         vc[(size_t)pos * D + tid] = vn[tid];
     }
+    // ---- scores: thread = position; sum over d in the reference's order (T:443-449) ----
     const float scale = 1.0f / sqrtf((float)D);
-    float mx = -INFINITY;
+    float mx[kMaxGroup];
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) mx[g] = -INFINITY;
     for (int j = tid; j < t_k; j += 256) {
-        const float *kr = j == pos ? kn : kc + (size_t)j * D;
-        float s = 0.0f;
-        for (int d = 0; d < D; d += 4) {
-            const float4 kv4 = *reinterpret_cast<const float4 *>(kr + d);
-            s += qs[d] * kv4.x;
-            s += qs[d + 1] * kv4.y;
-            s += qs[d + 2] * kv4.z;
-            s += qs[d + 3] * kv4.w;
+        float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j == pos) {
+            for (int d = 0; d < D; ++d) {
+                const float kv = kn[d];
+#pragma unroll
+                for (int g = 0; g < kMaxGroup; ++g) acc[g] += qs[g * D + d] * kv;
+            }
+        } else {
+            const float *kp = kt + j;
+#pragma unroll 16
+            for (int d = 0; d < D; ++d) {
+                const float kv = kp[(size_t)d * max_pos];
+#pragma unroll
+                for (int g = 0; g < kMaxGroup; ++g) acc[g] += qs[g * D + d] * kv;
+            }
         }
-        s *= scale;
-        sc[j] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) {
+            const float s = acc[g] * scale;
+            sc[g * max_pos + j] = s;
+            mx[g] = fmaxf(mx[g], s);
+        }
     }
-    mx = bmax(mx, slot);
-    float sum = 0.0f;
+    // ---- softmax over positions, per head (max-subtracted, T:495-508) ---------------------
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) mx[g] = wmax(mx[g]);
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) red[wave * kMaxGroup + g] = mx[g];
+    }
+    __syncthreads();
+    float sum[kMaxGroup];
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) {
+        mx[g] = fmaxf(fmaxf(red[g], red[kMaxGroup + g]), fmaxf(red[2 * kMaxGroup + g], red[3 * kMaxGroup + g]));
+        sum[g] = 0.0f;
+    }
     for (int j = tid; j < t_k; j += 256) {
-        const float e = expf(sc[j] - mx);
-        sc[j] = e;
-        sum += e;
-    }
-    sum = bsum(sum, slot);
-    for (int j = tid; j < t_k; j += 256) sc[j] = sc[j] / sum;
-    __syncthreads();
-    // P.V: thread (d, part) accumulates positions j = part, part + nparts, ...
-    const int nparts = 256 / D, d = tid % D, part = tid / D;
-    if (part < nparts) {
-        float acc = 0.0f;
-        for (int j = part; j < t_k; j += nparts) {
-            const float v = j == pos ? vn[d] : vc[(size_t)j * D + d];
-            acc += sc[j] * v;
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) {
+            const float e = expf(sc[g * max_pos + j] - mx[g]);
+            sc[g * max_pos + j] = e;
+            sum[g] += e;
         }
-        red[part * D + d] = acc;
+    }
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) sum[g] = wsum(sum[g]);
+    __syncthreads();  // everyone has read the max slots
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) red[wave * kMaxGroup + g] = sum[g];
     }
     __syncthreads();
-    if (tid < D) {
-        float acc = red[tid];
-        for (int pI = 1; pI < nparts; ++pI) acc += red[pI * D + tid];
-        out[(size_t)h * D + tid] = acc;
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g)
+        sum[g] = (red[g] + red[kMaxGroup + g]) + (red[2 * kMaxGroup + g] + red[3 * kMaxGroup + g]);
+    for (int j = tid; j < t_k; j += 256) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) sc[g * max_pos + j] = sc[g * max_pos + j] / sum[g];
+    }
+    __syncthreads();
+    // ---- P.V: thread = (dim d, head pair); positions in order (T:533) ---------------------
+    const int d = tid % D, hp = tid / D;  // D = 128: hp in {0,1} -> heads 2hp, 2hp+1
+    const int heads_per_thread = (kMaxGroup * D) / 256 > 0 ? (kMaxGroup * D) / 256 : 1;
+    for (int g0 = hp * heads_per_thread; g0 < group; g0 += (256 / D) * heads_per_thread) {
+        float a0 = 0.0f, a1 = 0.0f;
+        const float *p0 = sc + g0 * max_pos, *p1 = sc + (g0 + 1 < kMaxGroup ? g0 + 1 : g0) * max_pos;
+#pragma unroll 8
+        for (int j = 0; j < pos; ++j) {
+            const float v = vc[(size_t)j * D + d];
+            a0 += p0[j] * v;
+            a1 += p1[j] * v;
+        }
+        a0 += p0[pos] * vn[d];
+        a1 += p1[pos] * vn[d];
+        out[(size_t)(kvh * group + g0) * D + d] = a0;
+        if (heads_per_thread > 1 && g0 + 1 < group) out[(size_t)(kvh * group + g0 + 1) * D + d] = a1;
     }
 }
 
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
                               float *out, hipStream_t stream) {
-    if (D > 128 || 256 % D != 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(3 * D + 4 + 2 * D + max_pos) * sizeof(float);
+    if (D != 128 || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(kMaxGroup * D + 2 * D + 4 * kMaxGroup + kMaxGroup * max_pos) * sizeof(float);
     static size_t lds_allowed = 64 * 1024;  // raised once, outside any stream capture
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_decode),
@@ -191,7 +240,7 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(256), lds, stream, qkv, rope_sin, rope_cos, kcache, vcache,
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_kv), dim3(256), lds, stream, qkv, rope_sin, rope_cos, kcache, vcache,
                        n_heads, n_kv, D, max_pos, pos_ptr, out);
     return hipGetLastError();
 }
@@ -234,23 +283,42 @@ __global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     const int total_waves = gridDim.x * 4;
-    for (int row = blockIdx.x * 4 + wave; row < vocab; row += total_waves) {
-        const _Float16 *er = table + (size_t)row * hidden + 8 * lane;
-        float acc = 0.0f;
+    // two vocabulary rows per wave iteration: 2 x hidden x 2 B in flight per wave
+    for (int row = (blockIdx.x * 4 + wave) * 2; row < vocab; row += total_waves * 2) {
+        const bool two = row + 1 < vocab;
+        const _Float16 *e0 = table + (size_t)row * hidden + 8 * lane;
+        const _Float16 *e1 = table + (size_t)(two ? row + 1 : row) * hidden + 8 * lane;
+        float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int c = 0; c < kLogitChunks; ++c)
             if (c < nchunks) {
-                const half8 e = *reinterpret_cast<const half8 *>(er + 512 * c);
+                const half8 a = *reinterpret_cast<const half8 *>(e0 + 512 * c);
+                const half8 b = *reinterpret_cast<const half8 *>(e1 + 512 * c);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc += xr[c][i] * (float)e[i];
+                for (int i = 0; i < 8; ++i) {
+                    acc0 += xr[c][i] * (float)a[i];
+                    acc1 += xr[c][i] * (float)b[i];
+                }
             }
-        acc = wsum(acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc0 += __shfl_xor(acc0, off, 64);
+            acc1 += __shfl_xor(acc1, off, 64);
+        }
         if (lane == 0) {
-            logits[row] = acc;
-            const float v = acc != acc ? -INFINITY : acc;  // NaN -> -inf (sampling.rs:45-49)
+            logits[row] = acc0;
+            float v = acc0 != acc0 ? -INFINITY : acc0;  // NaN -> -inf (sampling.rs:45-49)
             if (v > bv || (v == bv && row < bi)) {
                 bv = v;
                 bi = row;
+            }
+            if (two) {
+                logits[row + 1] = acc1;
+                v = acc1 != acc1 ? -INFINITY : acc1;
+                if (v > bv || (v == bv && row + 1 < bi)) {
+                    bv = v;
+                    bi = row + 1;
+                }
             }
         }
     }

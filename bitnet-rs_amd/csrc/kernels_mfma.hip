@@ -54,19 +54,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #endif
 
 constexpr int kRing = 4;   // weight tiles (1 KiB each) a wave keeps in flight
-constexpr int kNVMAX = 8;  // float4 activation vectors per thread: K <= 8192
+constexpr int kNVMAX = 4;  // float4 activation vectors per thread (512 threads): K <= 8192
+constexpr int kWaves = 8;  // waves per workgroup
 
 struct MfmaArgs {
     const uint8_t *tiles;  // [n_tiles][nblk][64 lanes][16 B], fields transposed (k_retile)
     int rows, cols, nblk;  // nblk = ceil(cols / 256)
     uint32_t lut;
-    int ksplit;            // 1, 2 or 4 K ranges per row tile (waves of one workgroup)
+    int ksplit;            // 1, 2, 4 or 8 K ranges per row tile (waves of one workgroup)
     const float *x;        // [mt, cols]
     float *y;              // [mt, rows]  (silu_mul: [mt, rows/2])
     const float *ln_gamma; // optional LayerNorm prologue (T:67-100 semantics)
     float ln_eps;
     const float *residual; // optional: y = residual + W x
     const float *wscale;   // optional f32 scale per (row, 256-block)
+    const float *stiles;   // optional f32 scales per (row, 32-block), tiled [tile][blk][q][cg][half][j]
     int silu_mul;          // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     unsigned long long *stamps;  // diagnostic builds only
 };
@@ -81,20 +83,20 @@ __device__ __forceinline__ float wave_max_f(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-// Block-wide reductions over 4 waves; `slot` is a 4-float LDS scratch.
+// Block-wide reductions over the 8 waves, ONE barrier each: every call uses its own
+// 8-float LDS slot row, so a later call never overwrites values still being read.
 __device__ __forceinline__ float block_sum(float v, float *slot) {
     v = wave_sum_f(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    return ((slot[0] + slot[1]) + (slot[2] + slot[3])) + ((slot[4] + slot[5]) + (slot[6] + slot[7]));
 }
 __device__ __forceinline__ float block_max(float v, float *slot) {
     v = wave_max_f(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+    return fmaxf(fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3])),
+                 fmaxf(fmaxf(slot[4], slot[5]), fmaxf(slot[6], slot[7])));
 }
 
 // One dword = 16 codes (already field-transposed) -> the A operand of one MFMA:
@@ -125,19 +127,19 @@ __device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &
 }
 
 template <int MT>
-__global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
+__global__ __launch_bounds__(512) void k_gemv_mfma(MfmaArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int ps = p.nblk * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
     uint8_t *planes = lds;                                          // [4*MT][ps]
-    float *scratch = reinterpret_cast<float *>(lds + 4 * MT * ps);  // 4 reduce slots
-    float *inv_s = scratch + 4;                                     // [MT] (padded to 4)
-    float *part = scratch + 8;                                      // [4 waves][MT][16]
+    float *scratch = reinterpret_cast<float *>(lds + 4 * MT * ps);  // [3*MT][8] reduce slot rows
+    float *inv_s = scratch + 24 * MT;                               // [MT] (padded to 4)
+    float *part = inv_s + 4;                                        // [8 waves][MT][16]
     BH_STAMP(0);
 
     // ---- wave -> (row tile, K range) ------------------------------------------------
-    const int tiles_per_wg = 4 / p.ksplit;
+    const int tiles_per_wg = kWaves / p.ksplit;
     const int n_tiles = (p.rows + 15) >> 4;
     int tile = blockIdx.x * tiles_per_wg + wave / p.ksplit;
     tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
@@ -148,13 +150,13 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
     //         because vmcnt retires in order and these come from L2. ------------------
     const int nvec = (p.cols + 3) >> 2;
     float4 xr[kNVMAX], gr[kNVMAX];
-    const int nv_iters = (nvec + 255) >> 8;  // wave-uniform: unused unrolled iterations are branched over
+    const int nv_iters = (nvec + 511) >> 9;  // wave-uniform: unused unrolled iterations are branched over
     auto load_vec = [&](const float *src, float4 (&dst)[kNVMAX]) {
 #pragma unroll
         for (int i = 0; i < kNVMAX; ++i) {
             float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
             if (i < nv_iters) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + 512 * i;
                 if (idx < nvec) v = *reinterpret_cast<const float4 *>(src + 4 * idx);  // cols % 4 == 0
             }
             dst[i] = v;
@@ -165,10 +167,20 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
 
     // ---- 2. weight tiles: ring of kRing 1-KiB tiles in flight per wave ---------------
     const uint8_t *wbase = p.tiles + ((size_t)tile * p.nblk * 64 + lane) * 16;
+    // 32-element block scales ride along: 512 B per tile, 32 B per lane (8 floats: rows
+    // 4q..4q+3 of 32-blocks 2*cg and 2*cg+1 of this 256-block), shared by the 4 digit lanes
+    const float *sbase = p.stiles ? p.stiles + ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8 : nullptr;
     uint4 wt[kRing];
+    float4 s_lo[kRing], s_hi[kRing];
 #pragma unroll
     for (int j = 0; j < kRing; ++j)
-        if (b0 + j < b1) wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(b0 + j) * 1024);
+        if (b0 + j < b1) {
+            wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(b0 + j) * 1024);
+            if (sbase) {
+                s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(b0 + j) * 128);
+                s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(b0 + j) * 128 + 4);
+            }
+        }
     BH_STAMP(1);
 
     // ---- 3. prologue: [LayerNorm] -> fixed point -> digit planes in LDS --------------
@@ -182,12 +194,12 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
 #pragma unroll
             for (int i = 0; i < kNVMAX; ++i)
                 if (i < nv_iters) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
-            const float mean = block_sum(s, scratch) / (float)p.cols;
+            const float mean = block_sum(s, scratch + 24 * t) / (float)p.cols;
             float ss = 0.0f;
 #pragma unroll
             for (int i = 0; i < kNVMAX; ++i) {
                 if (i < nv_iters) {
-                    const bool in = tid + 256 * i < nvec;
+                    const bool in = tid + 512 * i < nvec;
                     xr[i].x = in ? xr[i].x - mean : 0.0f;
                     xr[i].y = in ? xr[i].y - mean : 0.0f;
                     xr[i].z = in ? xr[i].z - mean : 0.0f;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
                     ss += (xr[i].x * xr[i].x + xr[i].y * xr[i].y) + (xr[i].z * xr[i].z + xr[i].w * xr[i].w);
                 }
             }
-            const float denom = sqrtf(block_sum(ss, scratch) / (float)p.cols + p.ln_eps);
+            const float denom = sqrtf(block_sum(ss, scratch + 24 * t + 8) / (float)p.cols + p.ln_eps);
 #pragma unroll
             for (int i = 0; i < kNVMAX; ++i) {  // padded lanes hold 0 and gamma 0
                 if (i >= nv_iters) continue;
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
         for (int i = 0; i < kNVMAX; ++i)
             if (i < nv_iters)
                 am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[i].x), fabsf(xr[i].y))), fmaxf(fabsf(xr[i].z), fabsf(xr[i].w)));
-        am = block_max(am, scratch);
+        am = block_max(am, scratch + 24 * t + 16);
         BH_STAMP(2);
         // scale = 2^(29 - E), E = unbiased exponent of the row maximum (clamped so the
         // scale stays a normal float); |x * scale| < 2^30
@@ -220,8 +232,8 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
         if (tid == 0) inv_s[t] = __uint_as_float((uint32_t)(be - 29) << 23);
 #pragma unroll
         for (int i = 0; i < kNVMAX; ++i) {
-            const int idx = tid + 256 * i;
-            if (i < (p.nblk * 64 + 255) >> 8 && idx < p.nblk * 64) {  // zero digits up to the padded K: tail codes add 0
+            const int idx = tid + 512 * i;
+            if (i < (p.nblk * 64 + 511) >> 9 && idx < p.nblk * 64) {  // zero digits up to the padded K: tail codes add 0
                 uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
                 push_digits(xr[i].x, sc, 0, d0, d1, d2, d3);
                 push_digits(xr[i].y, sc, 1, d0, d1, d2, d3);
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
     // B operand of lane (col c = r16, k-group g): 16 bytes of plane c (MT=1: c & 3).
     const int plane = MT == 4 ? r16 : (r16 & 3);
     const uint8_t *bbase = planes + plane * ps + 64 * g;
+    const int bmask = (r16 >> 2) == g ? -1 : 0;  // 32-block mode: this lane's B is live for k-group c>>2 only
     v4i acc = {0, 0, 0, 0};
     float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c0 = b0; c0 < b1; c0 += kRing) {
@@ -249,8 +262,38 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
             const int blk = c0 + j;
             if (blk < b1) {
                 const uint32_t wd[4] = {wt[j].x, wt[j].y, wt[j].z, wt[j].w};
-                if (blk + kRing < b1)  // refill this ring slot right away
+                const float4 slo = s_lo[j], shi = s_hi[j];
+                if (blk + kRing < b1) {  // refill this ring slot right away
                     wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(blk + kRing) * 1024);
+                    if (sbase) {
+                        s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(blk + kRing) * 128);
+                        s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(blk + kRing) * 128 + 4);
+                    }
+                }
+                if (sbase) {
+                    // 32-element blocks: column c = 4*kg + d carries digit d of k-group kg only
+                    // (B is zero elsewhere), so D[row][c] is the exact integer sum over 16 k's;
+                    // MFMAs m = 0,1 complete 32-block 2*kg, m = 2,3 complete 2*kg + 1.
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const v4i a = decode16(wd[m], p.lut);
+                        v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * blk + 16 * m);
+                        b[0] &= bmask;
+                        b[1] &= bmask;
+                        b[2] &= bmask;
+                        b[3] &= bmask;
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+                        if (m & 1) {
+                            const float4 sv = m == 1 ? slo : shi;
+                            facc[0] += (float)acc[0] * sv.x;
+                            facc[1] += (float)acc[1] * sv.y;
+                            facc[2] += (float)acc[2] * sv.z;
+                            facc[3] += (float)acc[3] * sv.w;
+                            acc = (v4i){0, 0, 0, 0};
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const v4i a = decode16(wd[m], p.lut);
@@ -274,13 +317,17 @@ __global__ __launch_bounds__(256) void k_gemv_mfma(MfmaArgs p) {
     BH_STAMP(4);
 
     // ---- 5. epilogue: digits -> f32, K-range reduction, store ---------------------------
-    const float cw = (MT == 4 || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) : 0.0f;
+    const float cw = (MT == 4 || sbase || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) : 0.0f;
     float f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f[j] = (p.wscale ? facc[j] : (float)acc[j]) * cw;
+        f[j] = ((p.wscale || sbase) ? facc[j] : (float)acc[j]) * cw;
         f[j] += __shfl_xor(f[j], 1, 64);
         f[j] += __shfl_xor(f[j], 2, 64);
+        if (sbase) {  // 32-block mode: the four k-groups live in columns 4*kg + d
+            f[j] += __shfl_xor(f[j], 4, 64);
+            f[j] += __shfl_xor(f[j], 8, 64);
+        }
     }
     if ((r16 & 3) == 0 && (MT == 4 || r16 == 0)) {
         const int t = MT == 4 ? (r16 >> 2) : 0;
@@ -326,10 +373,11 @@ unsigned long long *g_mfma_stamps = nullptr;  // set through bitnet_hip_debug_se
 
 bool mfma_supported(const Weights &w) {
     if (w.cols == 0 || w.rows == 0) return false;
-    if (w.cols > (size_t)kNVMAX * 1024) return false;                    // prologue register budget
+    if (w.cols > (size_t)kNVMAX * 2048) return false;                    // prologue register budget
     if (w.cols % 4 != 0) return false;                                   // float4 activation loads
     if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;  // QK256-shaped rows
-    if (w.scales && w.block_size != 256) return false;                   // per-256-block f32 scales only
+    if (w.scales && w.block_size != 256 && w.block_size != 32) return false;  // f32 scales per 256- or 32-block
+    if (w.scales && w.block_size == 32 && w.cols % 256 != 0) return false;
     return true;
 }
 
@@ -338,8 +386,8 @@ int mfma_pick_ksplit(size_t rows, size_t cols, bool paired) {
     // spread over the 256 CUs (4 waves each, several workgroups per CU) without
     // leaving a wave fewer than ~2 tiles
     int ks = 1;
-    const int ks_max = paired ? 2 : 4;
-    while (ks < ks_max && n_tiles * ks < 4 * 256 && (size_t)ks * 2 * 2 <= nblk) ks *= 2;
+    const int ks_max = paired ? kWaves / 2 : kWaves;
+    while (ks < ks_max && (n_tiles * ks < 8 * 256 || div_ceil(nblk, ks) > (size_t)kRing) && (size_t)ks * 2 <= nblk) ks *= 2;
     return ks;
 }
 
@@ -355,10 +403,11 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul);
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
-    a.wscale = w.scales;
+    a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
+    a.stiles = (w.scales && w.block_size == 32) ? w.scale_tiles : nullptr;
     a.silu_mul = fu.silu_mul ? 1 : 0;
     a.stamps = g_mfma_stamps;
-    const int tiles_per_wg = 4 / a.ksplit;
+    const int tiles_per_wg = kWaves / a.ksplit;
     const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);
     const size_t out_rows = fu.silu_mul ? w.rows / 2 : w.rows;
     for (size_t m0 = 0; m0 < m;) {
@@ -366,18 +415,18 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
         a.x = x + m0 * w.cols;
         a.y = y + m0 * out_rows;
         a.residual = fu.residual ? fu.residual + m0 * w.rows : nullptr;
-        if (left >= 4) {
-            const size_t lds = (size_t)16 * (a.nblk * 256 + 16) + (8 + 4 * 4 * 16) * sizeof(float);
+        if (left >= 4 && !a.stiles) {
+            const size_t lds = (size_t)16 * (a.nblk * 256 + 16) + (24 * 4 + 4 + kWaves * 4 * 16) * sizeof(float);
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemv_mfma<4>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(k_gemv_mfma<4>, dim3(grid), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL(k_gemv_mfma<4>, dim3(grid), dim3(512), lds, stream, a);
             m0 += 4;
         } else {
-            const size_t lds = (size_t)4 * (a.nblk * 256 + 16) + (8 + 4 * 16) * sizeof(float);
-            hipLaunchKernelGGL(k_gemv_mfma<1>, dim3(grid), dim3(256), lds, stream, a);
+            const size_t lds = (size_t)4 * (a.nblk * 256 + 16) + (24 + 4 + kWaves * 16) * sizeof(float);
+            hipLaunchKernelGGL(k_gemv_mfma<1>, dim3(grid), dim3(512), lds, stream, a);
             m0 += 1;
         }
         hipError_t e = hipGetLastError();
@@ -417,7 +466,29 @@ __global__ void k_retile(const uint8_t *__restrict__ codes, size_t row_stride, i
     *reinterpret_cast<uint4 *>(tiles + i * 16) = v;
 }
 
+// scales [rows, cols/32] -> [tile][256-block][q][cg][half][j]: the 8 floats lane (q, cg) needs
+// for one 256-column block are contiguous (rows 4q+j, 32-blocks 2*cg + half).
+__global__ void k_retile_scales(const float *__restrict__ scales, int rows, int nblk, float *__restrict__ out,
+                                size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 3), half = (int)((i >> 2) & 1), cg = (int)((i >> 3) & 3), q = (int)((i >> 5) & 3);
+    const size_t tb = i >> 7;
+    const int blk = (int)(tb % nblk);
+    const size_t tile = tb / nblk;
+    const int row = (int)(16 * tile + 4 * q + j);
+    out[i] = row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * cg + half] : 0.0f;
+}
+
 hipError_t build_tiles(Weights &w, hipStream_t stream) {
+    if (w.scales && w.block_size == 32 && !w.scale_tiles) {
+        const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
+        const size_t total = n_tiles * nblk * 128;
+        hipError_t e = hipMalloc((void **)&w.scale_tiles, total * sizeof(float));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_retile_scales, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, w.scales,
+                           (int)w.rows, (int)nblk, w.scale_tiles, total);
+    }
     if (w.tiles) return hipSuccess;
     const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
     const size_t total16 = n_tiles * nblk * 64;

@@ -56,9 +56,12 @@ def ternary_weights(rows: int, cols: int, block: int, seed: int, layer: int, pro
     """Codes from {0,1,3} with P(0)=.5, P(+1)=P(-1)=.25 and scales 1/((i%100)+1)
     (crates/bitnet-quantization/benches/qk256_gemv.rs:41-43), scaled to keep O(1) outputs."""
     rng = _stream(seed, layer, proj, 1)
-    u = rng.integers(0, 4, (rows, cols), dtype=np.uint8)
-    codes = np.where(u < 2, 0, np.where(u == 2, 1, 3)).astype(np.uint8)
-    packed = (codes[:, 0::4] | (codes[:, 1::4] << 2) | (codes[:, 2::4] << 4) | (codes[:, 3::4] << 6)).astype(np.uint8)
+    assert cols % 4 == 0
+    # per 2-bit field: low bit ~ Bernoulli(.5) (code is odd: +-1), high bit = low & Bernoulli(.5)
+    # (code 3 = -1)  ->  P(0)=.5, P(1)=.25, P(3)=.25, never 2
+    a = rng.integers(0, 256, rows * cols // 4, dtype=np.uint8)
+    b = rng.integers(0, 256, rows * cols // 4, dtype=np.uint8)
+    packed = (a & 0x55) | (((a & b) & 0x55) << 1)
     nblk = -(-cols // block)
     scales = (2.0 / ((np.arange(rows * nblk) % 100) + 1)).astype(np.float32)
     return packed.reshape(-1), scales
