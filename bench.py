@@ -175,6 +175,10 @@ def main():
         "bytes_per_launch": int(abytes),
         "us_per_launch": round(us, 3),
     }
+    kernel_table = {}
+    for kind, name in enumerate(("qkv", "attention", "o_proj", "gate_up", "down", "logits")):
+        k_us, k_bytes = dec.probe_kernel(kind, 20)
+        kernel_table[name] = {"us_per_launch": round(k_us, 2), "GBps": round(k_bytes / k_us / 1e3, 1)}
     # whole-step view of the same metric: all I2_S matrices of one token / step time
     wb = dec.weight_bytes()
     i2s_gbs = wb / (elapsed / args.steps) / 1e9
@@ -208,6 +212,7 @@ def main():
             "i2s_weight_bytes_per_token": int(wb),
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "roofline": roofline,
+            "per_kernel": kernel_table,
             "last_tokens": [int(t) for t in tokens[-4:]],
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -116,7 +116,9 @@ class HipLib:
         L.bitnet_hip_norm_rows_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, C.c_float, C.c_int, _vp]
         L.bitnet_hip_embed_f16_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]
         L.bitnet_hip_advance_pos_dev.argtypes = [_vp, _vp]
-        L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
+        L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_attention_scratch_bytes.argtypes = [_sz, _sz]
+        L.bitnet_hip_attention_scratch_bytes.restype = _sz
         L.bitnet_hip_logits_f16_dev.argtypes = [_vp, _vp, _vp, C.c_float, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_argmax_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp]
 
@@ -268,8 +270,8 @@ class HipLib:
     def embed_f16_dev(self, table, tokens, out, n: int, hidden: int, vocab: int, offset=None, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_embed_f16_dev(_ptr(table), _ptr(tokens), _ptr(offset) if offset is not None else None, n, hidden, vocab, _ptr(out), _vp(stream)))
 
-    def attention_decode_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, out, stream: int = 0) -> None:
-        self._check(self.c.bitnet_hip_attention_decode_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(out), _vp(stream)))
+    def attention_decode_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_decode_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _ptr(out), _vp(stream)))
 
     def logits_f16_dev(self, table, x, gamma, eps, hidden, vocab, logits, scratch, n_wg, token=None, pos=None, history=None, n_forced=None, stream: int = 0) -> None:
         opt = lambda t: _ptr(t) if t is not None else None
@@ -339,6 +341,7 @@ class HostDecoder:
         L.bitnet_host_last_logits.argtypes = [C.c_void_p, _f32p]
         L.bitnet_host_last_hidden.argtypes = [C.c_void_p, _f32p]
         L.bitnet_host_probe_gateup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.bitnet_host_probe_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.bitnet_host_weight_bytes.argtypes = [C.c_void_p]
         L.bitnet_host_weight_bytes.restype = C.c_uint64
         self.cfg = cfg
@@ -411,6 +414,11 @@ class HostDecoder:
     def probe_gateup(self, reps: int):
         us, b = C.c_float(0), C.c_double(0)
         self._check(self.c.bitnet_host_probe_gateup(self.h, reps, C.byref(us), C.byref(b)))
+        return us.value, b.value
+
+    def probe_kernel(self, kind: int, reps: int):
+        us, b = C.c_float(0), C.c_double(0)
+        self._check(self.c.bitnet_host_probe_kernel(self.h, kind, reps, C.byref(us), C.byref(b)))
         return us.value, b.value
 
     def weight_bytes(self) -> int:

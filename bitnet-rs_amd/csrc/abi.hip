@@ -453,9 +453,9 @@ int bitnet_hip_embed_f16_dev(const void *table, const int32_t *tokens_dev, const
 
 int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                                     float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
-                                    const int32_t *pos_dev, float *out, void *stream) {
+                                    const int32_t *pos_dev, float *scratch, float *out, void *stream) {
     BH_GUARD_BEGIN
-    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !out)
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch || !out)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_dev");
     if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
@@ -463,9 +463,13 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
                          head_dim, n_heads / n_kv_heads);
     BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
-                                  (int)max_pos, pos_dev, out, (hipStream_t)stream));
+                                  (int)max_pos, pos_dev, scratch, out, (hipStream_t)stream));
     return BITNET_HIP_OK;
     BH_GUARD_END
+}
+
+size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos) {
+    return attn_scratch_floats((int)n_kv_heads, (int)max_pos) * sizeof(float);
 }
 
 int bitnet_hip_logits_f16_dev(const void *table, const float *x, const float *gamma, float eps, size_t hidden, size_t vocab,

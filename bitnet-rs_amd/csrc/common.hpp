@@ -101,7 +101,8 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
                             bool rms, hipStream_t stream);
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *out, hipStream_t stream);
+                              float *scratch, float *out, hipStream_t stream);
+size_t attn_scratch_floats(int n_kv, int max_pos);
 hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,
                              float *logits, float *best_val, int *best_idx, int n_wg, hipStream_t stream);
 hipError_t launch_argmax_final(const float *best_val, const int *best_idx, int n, int *token_out, int *pos_ptr,

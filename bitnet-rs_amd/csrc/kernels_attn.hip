@@ -1,0 +1,188 @@
+// kernels_attn.hip -- one-token attention for the decode step (gfx950): RoPE (T:134-163)
+// + KV append (T:1171-1202) + GQA softmax attention (T:410-533), split over 64-position
+// chunks of the context so the work spreads over many CUs and every load of a thread is
+// in flight at once (a per-head serial loop over the context is pure L2/HBM latency).
+//
+//   k_attn_partial  grid (n_kv, ceil(max_pos/64)): chunk-local scores, max m_c, exp-sum l_c
+//                   and un-normalised P.V partial o_c for the whole query group of one KV
+//                   head (each K/V element is read once per group);
+//   k_attn_combine  grid (n_kv): out = sum_c e^(m_c-M) o_c / sum_c e^(m_c-M) l_c.
+// Same value as the reference's softmax(QK^T/sqrt(d)) V up to f32 rounding.
+//
+// Cache layout (private to this library): K transposed, kcache[n_kv][D][max_pos] (the score
+// pass reads positions contiguously: lane = position); vcache[n_kv][max_pos][D] (the P.V pass
+// reads dims contiguously: lane = dim).  *pos_ptr = number of cached tokens.
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+constexpr int kAttnChunk = 64;
+constexpr int kMaxGroup = 4;
+constexpr int kD = 128;
+// per (kv head, chunk) record in the scratch buffer: m[4], l[4], o[4][128]
+constexpr int kRec = 2 * kMaxGroup + kMaxGroup * kD;
+
+template <int CTRL>
+__device__ __forceinline__ float adpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float arl(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float awave_max(float v) {
+    v = fmaxf(v, adpp<0xB1>(v));
+    v = fmaxf(v, adpp<0x4E>(v));
+    v = fmaxf(v, adpp<0x141>(v));
+    v = fmaxf(v, adpp<0x140>(v));
+    return fmaxf(fmaxf(arl(v, 0), arl(v, 16)), fmaxf(arl(v, 32), arl(v, 48)));
+}
+__device__ __forceinline__ float awave_sum(float v) {
+    v += adpp<0xB1>(v);
+    v += adpp<0x4E>(v);
+    v += adpp<0x141>(v);
+    v += adpp<0x140>(v);
+    return (arl(v, 0) + arl(v, 16)) + (arl(v, 32) + arl(v, 48));
+}
+
+__global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
+                                                      const float *__restrict__ rope_cos, float *__restrict__ kcache,
+                                                      float *__restrict__ vcache, int n_heads, int n_kv, int max_pos,
+                                                      const int *__restrict__ pos_ptr, float *__restrict__ scratch) {
+    const int pos = *pos_ptr, t_k = pos + 1;
+    const int kvh = blockIdx.x, pc = blockIdx.y, j0 = pc * kAttnChunk;
+    if (j0 >= t_k) return;  // chunk beyond the context (the grid is sized for max_pos)
+    __shared__ __attribute__((aligned(16))) float qs[kMaxGroup * kD];
+    __shared__ float kn[kD], vn[kD];
+    __shared__ float partial[4][kAttnChunk][kMaxGroup];
+    __shared__ float sc[kMaxGroup][kAttnChunk];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int group = n_heads / n_kv, half = kD / 2;
+    const bool owns_new = pos >= j0 && pos < j0 + kAttnChunk;
+    const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
+    // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------
+    {
+        const int g = tid >> 6, j = tid & 63;  // 4 heads x 64 rotation pairs = 256 threads
+        float a = 0.0f, b = 0.0f;
+        if (g < group) {
+            const float *q_raw = qkv + (size_t)(kvh * group + g) * kD;
+            const float s = sr[j], c = cr[j], q0 = q_raw[j], q1 = q_raw[half + j];
+            a = q0 * c - q1 * s;
+            b = q0 * s + q1 * c;
+        }
+        qs[g * kD + j] = a;
+        qs[g * kD + half + j] = b;
+    }
+    float *kt = kcache + (size_t)kvh * kD * max_pos;  // [D][max_pos]
+    float *vc = vcache + (size_t)kvh * max_pos * kD;  // [max_pos][D]
+    if (owns_new) {
+        if (tid < half) {
+            const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
+            const float s = sr[tid], c = cr[tid], k0 = k_raw[tid], k1 = k_raw[half + tid];
+            const float a = k0 * c - k1 * s, b = k0 * s + k1 * c;
+            kn[tid] = a;
+            kn[half + tid] = b;
+            kt[(size_t)tid * max_pos + pos] = a;  // append (transposed)
+            kt[(size_t)(half + tid) * max_pos + pos] = b;
+        } else if (tid >= 128) {
+            const float v = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid - 128)];
+            vn[tid - 128] = v;
+            vc[(size_t)pos * kD + (tid - 128)] = v;
+        }
+    }
+    __syncthreads();
+    // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
+    {
+        const int j = j0 + lane;
+        float kv[32];
+        const float *kp = kt + (size_t)(32 * wave) * max_pos + j;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) kv[i] = (j < pos) ? kp[(size_t)i * max_pos] : (j == pos ? kn[32 * wave + i] : 0.0f);
+        float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+#pragma unroll
+            for (int g = 0; g < kMaxGroup; ++g) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(qs + g * kD + 32 * wave + i);
+                acc[g] += q4.x * kv[i];
+                acc[g] += q4.y * kv[i + 1];
+                acc[g] += q4.z * kv[i + 2];
+                acc[g] += q4.w * kv[i + 3];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) partial[wave][lane][g] = acc[g];
+    }
+    __syncthreads();
+    // ---- chunk-local softmax pieces: wave g owns head g, lane = position ---------------------
+    const float scale = 1.0f / sqrtf((float)kD);
+    float m_c, l_c;
+    {
+        const int g = wave, j = j0 + lane;
+        float s = ((partial[0][lane][g] + partial[1][lane][g]) + partial[2][lane][g]) + partial[3][lane][g];
+        s = j < t_k ? s * scale : -INFINITY;
+        m_c = awave_max(s);
+        const float e = j < t_k ? expf(s - m_c) : 0.0f;
+        l_c = awave_sum(e);
+        sc[g][lane] = e;
+    }
+    __syncthreads();
+    // ---- un-normalised P.V: thread = (dim d, head pair); 64 independent V loads --------------
+    float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
+    {
+        const int d = tid & 127, hp = tid >> 7;
+        const int cnt = t_k - j0 < kAttnChunk ? t_k - j0 : kAttnChunk;
+        float a0 = 0.0f, a1 = 0.0f;
+        const float *vp = vc + (size_t)j0 * kD + d;
+#pragma unroll 16
+        for (int jj = 0; jj < kAttnChunk; ++jj) {
+            float v = 0.0f;
+            if (jj < cnt) v = (j0 + jj == pos) ? vn[d] : vp[(size_t)jj * kD];
+            a0 += sc[2 * hp][jj] * v;
+            a1 += sc[2 * hp + 1][jj] * v;
+        }
+        rec[2 * kMaxGroup + (2 * hp) * kD + d] = a0;
+        rec[2 * kMaxGroup + (2 * hp + 1) * kD + d] = a1;
+    }
+    if (lane == 0) {
+        rec[wave] = m_c;
+        rec[kMaxGroup + wave] = l_c;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_attn_combine(const float *__restrict__ scratch, int n_heads, int n_kv,
+                                                      int n_chunks_max, const int *__restrict__ pos_ptr,
+                                                      float *__restrict__ out) {
+    const int t_k = *pos_ptr + 1;
+    const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
+    const int kvh = blockIdx.x, group = n_heads / n_kv;
+    const int g = threadIdx.x >> 7, d = threadIdx.x & 127;  // 4 heads x 128 dims
+    if (g >= group) return;
+    const float *base = scratch + (size_t)kvh * n_chunks_max * kRec;
+    float M = -INFINITY;
+    for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, base[(size_t)c * kRec + g]);
+    float L = 0.0f, acc = 0.0f;
+    for (int c = 0; c < n_chunks; ++c) {
+        const float *rec = base + (size_t)c * kRec;
+        const float w = expf(rec[g] - M);
+        L += w * rec[kMaxGroup + g];
+        acc += w * rec[2 * kMaxGroup + g * kD + d];
+    }
+    out[(size_t)(kvh * group + g) * kD + d] = acc / L;
+}
+
+size_t attn_scratch_floats(int n_kv, int max_pos) {
+    return (size_t)n_kv * ((max_pos + kAttnChunk - 1) / kAttnChunk) * kRec;
+}
+
+hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                              float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
+                              float *scratch, float *out, hipStream_t stream) {
+    if (D != kD || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
+    const int n_chunks = (max_pos + kAttnChunk - 1) / kAttnChunk;
+    hipLaunchKernelGGL(k_attn_partial, dim3(n_kv, n_chunks), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
+                       vcache, n_heads, n_kv, max_pos, pos_ptr, scratch);
+    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv), dim3(512), 0, stream, scratch, n_heads, n_kv, n_chunks, pos_ptr, out);
+    return hipGetLastError();
+}
+
+}  // namespace bitnet_hip

@@ -95,156 +95,6 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
     return hipGetLastError();
 }
 
-// ---- one-token attention: RoPE (T:134-163) + KV append (T:1171-1202) + GQA softmax
-//      attention (T:410-533).  One workgroup per KV head serves its whole query group, so
-//      each K / V element is read once per group. -----------------------------------------
-// qkv: [n_heads*D | n_kv*D | n_kv*D] raw projections of the new token.
-// Cache layout (private to this library): K is kept TRANSPOSED, kcache[n_kv][D][max_pos],
-// so the score pass reads positions contiguously (thread = position, no shuffles);
-// vcache[n_kv][max_pos][D] so the P.V pass reads dims contiguously.  *pos_ptr = cached tokens.
-constexpr int kMaxGroup = 4;
-
-__global__ __launch_bounds__(256) void k_attn_decode(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
-                                                     const float *__restrict__ rope_cos, float *__restrict__ kcache,
-                                                     float *__restrict__ vcache, int n_heads, int n_kv, int D,
-                                                     int max_pos, const int *__restrict__ pos_ptr,
-                                                     float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int pos = *pos_ptr;
-    const int t_k = pos + 1;
-    const int kvh = blockIdx.x, group = n_heads / n_kv, half = D >> 1;
-    float *qs = sm;                     // [kMaxGroup][D] rotated queries of this group
-    float *kn = qs + kMaxGroup * D;     // [D] rotated new key
-    float *vn = kn + D;                 // [D] new value
-    float *red = vn + D;                // [4 waves][kMaxGroup] reduction scratch
-    float *sc = red + 4 * kMaxGroup;    // [kMaxGroup][max_pos] scores -> probabilities
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
-    for (int i = tid; i < group * half; i += 256) {  // RoPE on the group's queries
-        const int g = i / half, j = i % half;
-        const float *q_raw = qkv + (size_t)(kvh * group + g) * D;
-        const float s = sr[j], c = cr[j], q0 = q_raw[j], q1 = q_raw[half + j];
-        qs[g * D + j] = q0 * c - q1 * s;
-        qs[g * D + half + j] = q0 * s + q1 * c;
-    }
-    if (tid < half) {  // RoPE on the new key
-        const float *k_raw = qkv + (size_t)n_heads * D + (size_t)kvh * D;
-        const float s = sr[tid], c = cr[tid], k0 = k_raw[tid], k1 = k_raw[half + tid];
-        kn[tid] = k0 * c - k1 * s;
-        kn[half + tid] = k0 * s + k1 * c;
-    } else if (tid >= 128 && tid < 128 + D) {
-        vn[tid - 128] = qkv[(size_t)(n_heads + n_kv) * D + (size_t)kvh * D + (tid - 128)];
-    }
-    __syncthreads();
-    float *kt = kcache + (size_t)kvh * D * max_pos;  // [D][max_pos]
-    float *vc = vcache + (size_t)kvh * max_pos * D;  // [max_pos][D]
-    if (tid < D) {
-        kt[(size_t)tid * max_pos + pos] = kn[tid];
-        vc[(size_t)pos * D + tid] = vn[tid];
-    }
-    // ---- scores: thread = position; sum over d in the reference's order (T:443-449) ----
-    const float scale = 1.0f / sqrtf((float)D);
-    float mx[kMaxGroup];
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) mx[g] = -INFINITY;
-    for (int j = tid; j < t_k; j += 256) {
-        float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (j == pos) {
-            for (int d = 0; d < D; ++d) {
-                const float kv = kn[d];
-#pragma unroll
-                for (int g = 0; g < kMaxGroup; ++g) acc[g] += qs[g * D + d] * kv;
-            }
-        } else {
-            const float *kp = kt + j;
-#pragma unroll 16
-            for (int d = 0; d < D; ++d) {
-                const float kv = kp[(size_t)d * max_pos];
-#pragma unroll
-                for (int g = 0; g < kMaxGroup; ++g) acc[g] += qs[g * D + d] * kv;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) {
-            const float s = acc[g] * scale;
-            sc[g * max_pos + j] = s;
-            mx[g] = fmaxf(mx[g], s);
-        }
-    }
-    // ---- softmax over positions, per head (max-subtracted, T:495-508) ---------------------
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) mx[g] = wmax(mx[g]);
-    if (lane == 0) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) red[wave * kMaxGroup + g] = mx[g];
-    }
-    __syncthreads();
-    float sum[kMaxGroup];
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
-        mx[g] = fmaxf(fmaxf(red[g], red[kMaxGroup + g]), fmaxf(red[2 * kMaxGroup + g], red[3 * kMaxGroup + g]));
-        sum[g] = 0.0f;
-    }
-    for (int j = tid; j < t_k; j += 256) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) {
-            const float e = expf(sc[g * max_pos + j] - mx[g]);
-            sc[g * max_pos + j] = e;
-            sum[g] += e;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) sum[g] = wsum(sum[g]);
-    __syncthreads();  // everyone has read the max slots
-    if (lane == 0) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) red[wave * kMaxGroup + g] = sum[g];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g)
-        sum[g] = (red[g] + red[kMaxGroup + g]) + (red[2 * kMaxGroup + g] + red[3 * kMaxGroup + g]);
-    for (int j = tid; j < t_k; j += 256) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) sc[g * max_pos + j] = sc[g * max_pos + j] / sum[g];
-    }
-    __syncthreads();
-    // ---- P.V: thread = (dim d, head pair); positions in order (T:533) ---------------------
-    const int d = tid % D, hp = tid / D;  // D = 128: hp in {0,1} -> heads 2hp, 2hp+1
-    const int heads_per_thread = (kMaxGroup * D) / 256 > 0 ? (kMaxGroup * D) / 256 : 1;
-    for (int g0 = hp * heads_per_thread; g0 < group; g0 += (256 / D) * heads_per_thread) {
-        float a0 = 0.0f, a1 = 0.0f;
-        const float *p0 = sc + g0 * max_pos, *p1 = sc + (g0 + 1 < kMaxGroup ? g0 + 1 : g0) * max_pos;
-#pragma unroll 8
-        for (int j = 0; j < pos; ++j) {
-            const float v = vc[(size_t)j * D + d];
-            a0 += p0[j] * v;
-            a1 += p1[j] * v;
-        }
-        a0 += p0[pos] * vn[d];
-        a1 += p1[pos] * vn[d];
-        out[(size_t)(kvh * group + g0) * D + d] = a0;
-        if (heads_per_thread > 1 && g0 + 1 < group) out[(size_t)(kvh * group + g0 + 1) * D + d] = a1;
-    }
-}
-
-hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
-                              float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *out, hipStream_t stream) {
-    if (D != 128 || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(kMaxGroup * D + 2 * D + 4 * kMaxGroup + kMaxGroup * max_pos) * sizeof(float);
-    static size_t lds_allowed = 64 * 1024;  // raised once, outside any stream capture
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_decode),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_kv), dim3(256), lds, stream, qkv, rope_sin, rope_cos, kcache, vcache,
-                       n_heads, n_kv, D, max_pos, pos_ptr, out);
-    return hipGetLastError();
-}
-
 // ---- tied-embedding logits (T:1599-1630) with fused final LayerNorm and per-workgroup
 //      argmax partials (crates/bitnet-cli/src/sampling.rs:189-202) ----------------------------
 // logits[v] = sum_k LN(x)[k] * (float)E[v,k].  One wave per vocabulary row, grid-strided;

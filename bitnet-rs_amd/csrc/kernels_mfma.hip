@@ -30,6 +30,9 @@
 // (measured: ~30-90 ns per 64-byte line of straight-line code), so the kernel is
 // written for a small instruction footprint: a 4-deep register ring of weight tiles
 // instead of a fully unrolled K loop, runtime flags instead of template variants.
+#include <cstdlib>
+#include <unordered_set>
+
 #include "common.hpp"
 
 namespace bitnet_hip {
@@ -54,8 +57,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #endif
 
 constexpr int kRing = 4;   // weight tiles (1 KiB each) a wave keeps in flight
-constexpr int kNVMAX = 4;  // float4 activation vectors per thread (512 threads): K <= 8192
-constexpr int kWaves = 8;  // waves per workgroup
+constexpr int kNVMAX = 4;  // float4 LayerNorm-statistics vectors per thread (512 threads): K <= 8192
+constexpr int kWaves = 8;  // waves per workgroup (kernel template NW: 8, or 16 for many-tile launches)
 
 struct MfmaArgs {
     const uint8_t *tiles;  // [n_tiles][nblk][64 lanes][16 B], fields transposed (k_retile)
@@ -73,30 +76,43 @@ struct MfmaArgs {
     unsigned long long *stamps;  // diagnostic builds only
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// ---- wave-64 reductions on DPP (no LDS crossbar): 4 row steps + 4 readlanes -------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 __device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    double r[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-// Block-wide reductions over the 8 waves, ONE barrier each: every call uses its own
-// 8-float LDS slot row, so a later call never overwrites values still being read.
-__device__ __forceinline__ float block_sum(float v, float *slot) {
-    v = wave_sum_f(v);
-    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ((slot[0] + slot[1]) + (slot[2] + slot[3])) + ((slot[4] + slot[5]) + (slot[6] + slot[7]));
-}
-__device__ __forceinline__ float block_max(float v, float *slot) {
-    v = wave_max_f(v);
-    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmaxf(fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3])),
-                 fmaxf(fmaxf(slot[4], slot[5]), fmaxf(slot[6], slot[7])));
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * i);
+        r[i] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // One dword = 16 codes (already field-transposed) -> the A operand of one MFMA:
@@ -126,243 +142,252 @@ __device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &
     d3 |= (uint32_t)(q & 0xff) << (8 * b);
 }
 
-template <int MT>
-__global__ __launch_bounds__(512) void k_gemv_mfma(MfmaArgs p) {
+// NW waves per workgroup, RING = 256-column blocks per wave (all in flight at once), NV =
+// float4 LayerNorm-statistics vectors per thread, LN = fused LayerNorm prologue, BS32 =
+// 32-element block scales.  They are template parameters, and every global load below is
+// UNCONDITIONAL (indices clamped, values masked afterwards), so that hipcc can count the
+// outstanding loads: with a load inside any branch it falls back to s_waitcnt vmcnt(0) at the
+// first use of the activations, i.e. waits for the whole weight stream before the prologue.
+template <int NW, int RING, int NV, bool LN, bool BS32>
+__global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int ps = p.nblk * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
-    uint8_t *planes = lds;                                          // [4*MT][ps]
-    float *scratch = reinterpret_cast<float *>(lds + 4 * MT * ps);  // [3*MT][8] reduce slot rows
-    float *inv_s = scratch + 24 * MT;                               // [MT] (padded to 4)
-    float *part = inv_s + 4;                                        // [8 waves][MT][16]
+    constexpr int ps = RING * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
+    uint8_t *planes = lds + wave * 4 * ps;                          // this wave's [4][ps]
+    double *stat = reinterpret_cast<double *>(lds + NW * 4 * ps);   // [NW][2] LayerNorm sums
+    float *part = reinterpret_cast<float *>(stat + 2 * NW);         // [NW][16]
+    float *vbuf = part + NW * 16;                                   // [cols] normalised row (LN only)
     BH_STAMP(0);
 
-    // ---- wave -> (row tile, K range) ------------------------------------------------
-    const int tiles_per_wg = kWaves / p.ksplit;
+    // ---- wave -> (row tile, K range of at most RING 256-column blocks) ------------------
+    const int tiles_per_wg = NW / p.ksplit;
     const int n_tiles = (p.rows + 15) >> 4;
     int tile = blockIdx.x * tiles_per_wg + wave / p.ksplit;
     tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
     const int kpart = wave % p.ksplit;
     const int b0 = (kpart * p.nblk) / p.ksplit, b1 = ((kpart + 1) * p.nblk) / p.ksplit;
+    const int nvec = p.cols >> 2;  // cols % 4 == 0
 
-    // ---- 1. activation row 0: global -> registers.  Issued before the weight loads
-    //         because vmcnt retires in order and these come from L2. ------------------
-    const int nvec = (p.cols + 3) >> 2;
-    float4 xr[kNVMAX], gr[kNVMAX];
-    const int nv_iters = (nvec + 511) >> 9;  // wave-uniform: unused unrolled iterations are branched over
-    auto load_vec = [&](const float *src, float4 (&dst)[kNVMAX]) {
+    // ---- 1. activations first (vmcnt retires in order; these come from L2) ---------------
+    float4 xr[RING];
+    float4 sx[NV], sg[NV];
+    if (LN) {
+        // LayerNorm needs the whole row: the workgroup reads x and gamma ONCE (each thread its
+        // share) and hands the normalised row to the waves through LDS.
 #pragma unroll
-        for (int i = 0; i < kNVMAX; ++i) {
-            float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (i < nv_iters) {
-                const int idx = tid + 512 * i;
-                if (idx < nvec) v = *reinterpret_cast<const float4 *>(src + 4 * idx);  // cols % 4 == 0
-            }
-            dst[i] = v;
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            const int ci = idx < nvec ? idx : nvec - 1;
+            sx[i] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+            sg[i] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
         }
-    };
-    load_vec(p.x, xr);
-    if (p.ln_gamma) load_vec(p.ln_gamma, gr);
+    } else {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int idx = (b0 + j) * 64 + lane;
+            const int ci = idx < nvec ? idx : nvec - 1;
+            xr[j] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+        }
+    }
 
-    // ---- 2. weight tiles: ring of kRing 1-KiB tiles in flight per wave ---------------
+    // ---- 2. weight tiles: RING 1-KiB tiles in flight per wave ------------------------------
     const uint8_t *wbase = p.tiles + ((size_t)tile * p.nblk * 64 + lane) * 16;
     // 32-element block scales ride along: 512 B per tile, 32 B per lane (8 floats: rows
     // 4q..4q+3 of 32-blocks 2*cg and 2*cg+1 of this 256-block), shared by the 4 digit lanes
-    const float *sbase = p.stiles ? p.stiles + ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8 : nullptr;
-    uint4 wt[kRing];
-    float4 s_lo[kRing], s_hi[kRing];
+    const float *sbase = BS32 ? p.stiles + ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8 : nullptr;
+    uint4 wt[RING];
+    float4 s_lo[RING], s_hi[RING];
 #pragma unroll
-    for (int j = 0; j < kRing; ++j)
-        if (b0 + j < b1) {
-            wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(b0 + j) * 1024);
-            if (sbase) {
-                s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(b0 + j) * 128);
-                s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(b0 + j) * 128 + 4);
-            }
-        }
-    BH_STAMP(1);
-
-    // ---- 3. prologue: [LayerNorm] -> fixed point -> digit planes in LDS --------------
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        if (t > 0) load_vec(p.x + (size_t)t * p.cols, xr);
-        if (p.ln_gamma) {
-            // LayerNorm without bias, WITH mean subtraction (T:89-97; candle LayerNorm
-            // slow path): (x - mean) / sqrt(mean((x - mean)^2) + eps) * gamma
-            float s = 0.0f;
-#pragma unroll
-            for (int i = 0; i < kNVMAX; ++i)
-                if (i < nv_iters) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
-            const float mean = block_sum(s, scratch + 24 * t) / (float)p.cols;
-            float ss = 0.0f;
-#pragma unroll
-            for (int i = 0; i < kNVMAX; ++i) {
-                if (i < nv_iters) {
-                    const bool in = tid + 512 * i < nvec;
-                    xr[i].x = in ? xr[i].x - mean : 0.0f;
-                    xr[i].y = in ? xr[i].y - mean : 0.0f;
-                    xr[i].z = in ? xr[i].z - mean : 0.0f;
-                    xr[i].w = in ? xr[i].w - mean : 0.0f;
-                    ss += (xr[i].x * xr[i].x + xr[i].y * xr[i].y) + (xr[i].z * xr[i].z + xr[i].w * xr[i].w);
-                }
-            }
-            const float denom = sqrtf(block_sum(ss, scratch + 24 * t + 8) / (float)p.cols + p.ln_eps);
-#pragma unroll
-            for (int i = 0; i < kNVMAX; ++i) {  // padded lanes hold 0 and gamma 0
-                if (i >= nv_iters) continue;
-                xr[i].x = xr[i].x / denom * gr[i].x;
-                xr[i].y = xr[i].y / denom * gr[i].y;
-                xr[i].z = xr[i].z / denom * gr[i].z;
-                xr[i].w = xr[i].w / denom * gr[i].w;
-            }
-        }
-        float am = 0.0f;
-#pragma unroll
-        for (int i = 0; i < kNVMAX; ++i)
-            if (i < nv_iters)
-                am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[i].x), fabsf(xr[i].y))), fmaxf(fabsf(xr[i].z), fabsf(xr[i].w)));
-        am = block_max(am, scratch + 24 * t + 16);
-        BH_STAMP(2);
-        // scale = 2^(29 - E), E = unbiased exponent of the row maximum (clamped so the
-        // scale stays a normal float); |x * scale| < 2^30
-        int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
-        be = be < 32 ? 32 : be;
-        const float sc = __uint_as_float((uint32_t)(283 - be) << 23);
-        if (tid == 0) inv_s[t] = __uint_as_float((uint32_t)(be - 29) << 23);
-#pragma unroll
-        for (int i = 0; i < kNVMAX; ++i) {
-            const int idx = tid + 512 * i;
-            if (i < (p.nblk * 64 + 511) >> 9 && idx < p.nblk * 64) {  // zero digits up to the padded K: tail codes add 0
-                uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-                push_digits(xr[i].x, sc, 0, d0, d1, d2, d3);
-                push_digits(xr[i].y, sc, 1, d0, d1, d2, d3);
-                push_digits(xr[i].z, sc, 2, d0, d1, d2, d3);
-                push_digits(xr[i].w, sc, 3, d0, d1, d2, d3);
-                *reinterpret_cast<uint32_t *>(planes + (4 * t + 0) * ps + 4 * idx) = d0;
-                *reinterpret_cast<uint32_t *>(planes + (4 * t + 1) * ps + 4 * idx) = d1;
-                *reinterpret_cast<uint32_t *>(planes + (4 * t + 2) * ps + 4 * idx) = d2;
-                *reinterpret_cast<uint32_t *>(planes + (4 * t + 3) * ps + 4 * idx) = d3;
-            }
+    for (int j = 0; j < RING; ++j) {
+        const int blk = b0 + j < b1 ? b0 + j : b1 - 1;  // clamped: a short range re-reads its last tile
+        wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)blk * 1024);
+        if (BS32) {
+            s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128);
+            s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128 + 4);
         }
     }
-    __syncthreads();
+    BH_STAMP(1);
+
+    // ---- 3. prologue: [LayerNorm] -> fixed point -> this wave's digit planes --------------
+    if (LN) {
+        // LayerNorm without bias, WITH mean subtraction (T:89-97; candle LayerNorm slow path):
+        // (x - mean) / sqrt(mean((x - mean)^2) + eps) * gamma.  One pass: sum and sum of
+        // squares in f64 (products of f32 are exact in f64).
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool in = tid + NT * i < nvec;
+            const double a = in ? sx[i].x : 0.0f, b = in ? sx[i].y : 0.0f, c = in ? sx[i].z : 0.0f, d = in ? sx[i].w : 0.0f;
+            s1 += (a + b) + (c + d);
+            s2 += (a * a + b * b) + (c * c + d * d);
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane == 0) {
+            stat[2 * wave] = s1;
+            stat[2 * wave + 1] = s2;
+        }
+        __syncthreads();
+        s1 = 0.0;
+        s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            s1 += stat[2 * w];
+            s2 += stat[2 * w + 1];
+        }
+        const double mean_d = s1 / (double)p.cols;
+        const double var_d = s2 / (double)p.cols - mean_d * mean_d;
+        const float mean = (float)mean_d;
+        const float denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < nvec) {
+                float4 v;
+                v.x = (sx[i].x - mean) / denom * sg[i].x;
+                v.y = (sx[i].y - mean) / denom * sg[i].y;
+                v.z = (sx[i].z - mean) / denom * sg[i].z;
+                v.w = (sx[i].w - mean) / denom * sg[i].w;
+                *reinterpret_cast<float4 *>(vbuf + 4 * idx) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int idx = (b0 + j) * 64 + lane;
+            xr[j] = *reinterpret_cast<const float4 *>(vbuf + 4 * (idx < nvec ? idx : nvec - 1));
+        }
+    }
+    float am = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+        if (!(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[j].x), fabsf(xr[j].y))), fmaxf(fabsf(xr[j].z), fabsf(xr[j].w)));
+    }
+    am = wave_max_f(am);  // this wave's K range only: the scale is per wave
+    BH_STAMP(2);
+    // scale = 2^(29 - E), E = unbiased exponent of the maximum (clamped so the scale stays a
+    // normal float); |x * scale| < 2^30
+    int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
+    be = be < 32 ? 32 : be;
+    const float sc = __uint_as_float((uint32_t)(283 - be) << 23);
+    const float inv_s = __uint_as_float((uint32_t)(be - 29) << 23);
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        push_digits(xr[j].x, sc, 0, d0, d1, d2, d3);
+        push_digits(xr[j].y, sc, 1, d0, d1, d2, d3);
+        push_digits(xr[j].z, sc, 2, d0, d1, d2, d3);
+        push_digits(xr[j].w, sc, 3, d0, d1, d2, d3);
+        const int pos = 256 * j + 4 * lane;
+        *reinterpret_cast<uint32_t *>(planes + 0 * ps + pos) = d0;
+        *reinterpret_cast<uint32_t *>(planes + 1 * ps + pos) = d1;
+        *reinterpret_cast<uint32_t *>(planes + 2 * ps + pos) = d2;
+        *reinterpret_cast<uint32_t *>(planes + 3 * ps + pos) = d3;
+    }
     BH_STAMP(3);
 
-    // ---- 4. main loop: decode -> MFMA --------------------------------------------------
-    // B operand of lane (col c = r16, k-group g): 16 bytes of plane c (MT=1: c & 3).
-    const int plane = MT == 4 ? r16 : (r16 & 3);
-    const uint8_t *bbase = planes + plane * ps + 64 * g;
+    // ---- 4. main loop: decode -> MFMA.  The planes are this wave's own: LDS executes one
+    //         wave's accesses in order, no barrier needed.  Slots past the wave's range hold
+    //         zero digits (and a re-read tile), so they add exact zeros. ----------------------
+    // B operand of lane (col c = r16, k-group g): 16 bytes of plane c & 3.
+    const uint8_t *bbase = planes + (r16 & 3) * ps + 64 * g;
     const int bmask = (r16 >> 2) == g ? -1 : 0;  // 32-block mode: this lane's B is live for k-group c>>2 only
     v4i acc = {0, 0, 0, 0};
     float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c0 = b0; c0 < b1; c0 += kRing) {
 #pragma unroll
-        for (int j = 0; j < kRing; ++j) {
-            const int blk = c0 + j;
-            if (blk < b1) {
-                const uint32_t wd[4] = {wt[j].x, wt[j].y, wt[j].z, wt[j].w};
-                const float4 slo = s_lo[j], shi = s_hi[j];
-                if (blk + kRing < b1) {  // refill this ring slot right away
-                    wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)(blk + kRing) * 1024);
-                    if (sbase) {
-                        s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(blk + kRing) * 128);
-                        s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)(blk + kRing) * 128 + 4);
-                    }
-                }
-                if (sbase) {
-                    // 32-element blocks: column c = 4*kg + d carries digit d of k-group kg only
-                    // (B is zero elsewhere), so D[row][c] is the exact integer sum over 16 k's;
-                    // MFMAs m = 0,1 complete 32-block 2*kg, m = 2,3 complete 2*kg + 1.
+    for (int j = 0; j < RING; ++j) {
+        const uint32_t wd[4] = {wt[j].x, wt[j].y, wt[j].z, wt[j].w};
+        if (BS32) {
+            // 32-element blocks: column c = 4*kg + d carries digit d of k-group kg only (B is
+            // zero elsewhere), so D[row][c] is the exact integer sum over 16 k's; MFMAs
+            // m = 0,1 complete 32-block 2*kg, m = 2,3 complete 2*kg + 1.
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const v4i a = decode16(wd[m], p.lut);
-                        v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * blk + 16 * m);
-                        b[0] &= bmask;
-                        b[1] &= bmask;
-                        b[2] &= bmask;
-                        b[3] &= bmask;
-                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
-                        if (m & 1) {
-                            const float4 sv = m == 1 ? slo : shi;
-                            facc[0] += (float)acc[0] * sv.x;
-                            facc[1] += (float)acc[1] * sv.y;
-                            facc[2] += (float)acc[2] * sv.z;
-                            facc[3] += (float)acc[3] * sv.w;
-                            acc = (v4i){0, 0, 0, 0};
-                        }
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const v4i a = decode16(wd[m], p.lut);
-                    const v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * blk + 16 * m);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
-                }
-                if (p.wscale) {
-                    // one f32 weight scale per (row, 256-block): fold this block's exact
-                    // integer sums into f32 accumulators (rows 4g+j of the tile)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        int row = 16 * tile + 4 * g + jj;
-                        row = row < p.rows ? row : p.rows - 1;
-                        facc[jj] += (float)acc[jj] * p.wscale[(size_t)row * p.nblk + blk];
-                    }
+            for (int m = 0; m < 4; ++m) {
+                const v4i a = decode16(wd[m], p.lut);
+                v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * j + 16 * m);
+                b[0] &= bmask;
+                b[1] &= bmask;
+                b[2] &= bmask;
+                b[3] &= bmask;
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+                if (m & 1) {
+                    const float4 sv = m == 1 ? s_lo[j] : s_hi[j];
+                    facc[0] += (float)acc[0] * sv.x;
+                    facc[1] += (float)acc[1] * sv.y;
+                    facc[2] += (float)acc[2] * sv.z;
+                    facc[3] += (float)acc[3] * sv.w;
                     acc = (v4i){0, 0, 0, 0};
                 }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const v4i a = decode16(wd[m], p.lut);
+                const v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * j + 16 * m);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+            }
+            if (p.wscale) {
+                // one f32 weight scale per (row, 256-block): fold this block's exact integer
+                // sums into f32 accumulators (rows 4g+j of the tile)
+                const int blk = b0 + j < b1 ? b0 + j : b1 - 1;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    int row = 16 * tile + 4 * g + jj;
+                    row = row < p.rows ? row : p.rows - 1;
+                    facc[jj] += (float)acc[jj] * p.wscale[(size_t)row * p.nblk + blk];
+                }
+                acc = (v4i){0, 0, 0, 0};
             }
         }
     }
     BH_STAMP(4);
 
-    // ---- 5. epilogue: digits -> f32, K-range reduction, store ---------------------------
-    const float cw = (MT == 4 || sbase || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) : 0.0f;
+    // ---- 5. epilogue: digits -> f32 (x this wave's 2^(E-29)), K-range reduction, store -----
+    const float cw = (BS32 || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) * inv_s : 0.0f;
     float f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f[j] = ((p.wscale || sbase) ? facc[j] : (float)acc[j]) * cw;
-        f[j] += __shfl_xor(f[j], 1, 64);
-        f[j] += __shfl_xor(f[j], 2, 64);
-        if (sbase) {  // 32-block mode: the four k-groups live in columns 4*kg + d
-            f[j] += __shfl_xor(f[j], 4, 64);
-            f[j] += __shfl_xor(f[j], 8, 64);
+        f[j] = ((p.wscale || BS32) ? facc[j] : (float)acc[j]) * cw;
+        f[j] += dpp_f<0xB1>(f[j]);  // lanes c ^ 1
+        f[j] += dpp_f<0x4E>(f[j]);  // lanes c ^ 2: the four digit columns
+        if (BS32) {                 // the four k-groups live in columns 4*kg + d
+            f[j] += dpp_f<0x141>(f[j]);
+            f[j] += dpp_f<0x140>(f[j]);
         }
     }
-    if ((r16 & 3) == 0 && (MT == 4 || r16 == 0)) {
-        const int t = MT == 4 ? (r16 >> 2) : 0;
+    if (r16 == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(wave * MT + t) * 16 + 4 * g + j] = f[j];
+        for (int j = 0; j < 4; ++j) part[wave * 16 + 4 * g + j] = f[j];
     }
     __syncthreads();
     if (!p.silu_mul) {
-        if (tid < tiles_per_wg * MT * 16) {
-            const int tl = tid / (MT * 16), t = (tid / 16) % MT, r = tid & 15;
+        if (tid < tiles_per_wg * 16) {
+            const int tl = tid >> 4, r = tid & 15;
             const int row = 16 * (blockIdx.x * tiles_per_wg + tl) + r;
             if (row < p.rows) {
                 float v = 0.0f;
-                for (int kp = 0; kp < p.ksplit; ++kp) v += part[((tl * p.ksplit + kp) * MT + t) * 16 + r];
-                v *= inv_s[t];
-                if (p.residual) v += p.residual[(size_t)t * p.rows + row];
-                p.y[(size_t)t * p.rows + row] = v;
+                for (int kp = 0; kp < p.ksplit; ++kp) v += part[(tl * p.ksplit + kp) * 16 + r];
+                if (p.residual) v += p.residual[row];
+                p.y[row] = v;
             }
         }
     } else {
         // rows come in (gate tile, up tile) pairs; FeedForward::forward T:756-781:
         // hidden = silu(gate) * up, silu(v) = v / (1 + exp(-v))
         const int pairs_per_wg = tiles_per_wg / 2, half_rows = p.rows / 2;
-        if (tid < pairs_per_wg * MT * 16) {
-            const int pl = tid / (MT * 16), t = (tid / 16) % MT, r = tid & 15;
+        if (tid < pairs_per_wg * 16) {
+            const int pl = tid >> 4, r = tid & 15;
             const int row = 16 * (blockIdx.x * pairs_per_wg + pl) + r;
             if (row < half_rows) {
                 float gv = 0.0f, uv = 0.0f;
                 for (int kp = 0; kp < p.ksplit; ++kp) {
-                    gv += part[(((2 * pl) * p.ksplit + kp) * MT + t) * 16 + r];
-                    uv += part[(((2 * pl + 1) * p.ksplit + kp) * MT + t) * 16 + r];
+                    gv += part[((2 * pl) * p.ksplit + kp) * 16 + r];
+                    uv += part[((2 * pl + 1) * p.ksplit + kp) * 16 + r];
                 }
-                gv *= inv_s[t];
-                uv *= inv_s[t];
-                p.y[(size_t)t * half_rows + row] = gv / (1.0f + expf(-gv)) * uv;
+                p.y[row] = gv / (1.0f + expf(-gv)) * uv;
             }
         }
     }
@@ -378,15 +403,17 @@ bool mfma_supported(const Weights &w) {
     if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;  // QK256-shaped rows
     if (w.scales && w.block_size != 256 && w.block_size != 32) return false;  // f32 scales per 256- or 32-block
     if (w.scales && w.block_size == 32 && w.cols % 256 != 0) return false;
+    if (div_ceil(div_ceil(w.cols, 256), (size_t)(w.paired ? 4 : 8)) > (size_t)kRing) return false;  // K range per wave
     return true;
 }
 
-int mfma_pick_ksplit(size_t rows, size_t cols, bool paired) {
+int mfma_pick_ksplit(size_t rows, size_t cols, bool paired, int nw) {
     const size_t n_tiles = div_ceil(rows, 16), nblk = div_ceil(cols, 256);
     // spread over the 256 CUs (4 waves each, several workgroups per CU) without
     // leaving a wave fewer than ~2 tiles
     int ks = 1;
-    const int ks_max = paired ? kWaves / 2 : kWaves;
+    const int ks_max = paired ? 4 : 8;  // K ranges per row tile (<= waves per workgroup)
+    (void)nw;
     while (ks < ks_max && (n_tiles * ks < 8 * 256 || div_ceil(nblk, ks) > (size_t)kRing) && (size_t)ks * 2 <= nblk) ks *= 2;
     return ks;
 }
@@ -400,35 +427,49 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.cols = (int)w.cols;
     a.nblk = (int)div_ceil(w.cols, 256);
     a.lut = w.lut;
-    a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul);
+    // many row tiles: 16-wave workgroups, one per CU, so no second workgroup's activation loads
+    // queue behind the first one's weight stream in the CU's memory pipeline
+    const int nw = (getenv("BITNET_HIP_NW16") && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
+    a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
     a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
     a.stiles = (w.scales && w.block_size == 32) ? w.scale_tiles : nullptr;
     a.silu_mul = fu.silu_mul ? 1 : 0;
     a.stamps = g_mfma_stamps;
-    const int tiles_per_wg = kWaves / a.ksplit;
+    const int tiles_per_wg = nw / a.ksplit;
     const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);
     const size_t out_rows = fu.silu_mul ? w.rows / 2 : w.rows;
-    for (size_t m0 = 0; m0 < m;) {
-        const size_t left = m - m0;
+    // template selection: RING = blocks per wave, NV = statistics float4 per thread
+    const int ring = (int)div_ceil((size_t)a.nblk, (size_t)a.ksplit);
+    const bool ln = fu.ln_gamma != nullptr, bs32 = a.stiles != nullptr;
+    const int nv = ln ? (int)div_ceil(w.cols / 4, (size_t)nw * 64) : 1;
+    if (ring > kRing || nv > kNVMAX) return hipErrorInvalidValue;
+    void (*kfn)(MfmaArgs) = nullptr;
+#define BH_PICK(NWv, RINGv, NVv)                                                                          \
+    if (nw == NWv && ring <= RINGv && nv <= NVv && !kfn)                                                  \
+        kfn = ln ? (bs32 ? k_gemv_mfma<NWv, RINGv, NVv, true, true> : k_gemv_mfma<NWv, RINGv, NVv, true, false>) \
+                 : (bs32 ? k_gemv_mfma<NWv, RINGv, 1, false, true> : k_gemv_mfma<NWv, RINGv, 1, false, false>);
+    BH_PICK(8, 2, 2) BH_PICK(8, 2, 4) BH_PICK(8, 3, 2) BH_PICK(8, 3, 4) BH_PICK(8, 4, 2) BH_PICK(8, 4, 4)
+    BH_PICK(16, 2, 1) BH_PICK(16, 2, 2) BH_PICK(16, 3, 1) BH_PICK(16, 3, 2) BH_PICK(16, 4, 1) BH_PICK(16, 4, 2)
+#undef BH_PICK
+    if (!kfn) return hipErrorInvalidValue;
+    const int ring_t = ring <= 2 ? 2 : ring;  // the instantiated RING (LDS plane stride)
+    const size_t lds = (size_t)nw * 4 * (ring_t * 256 + 16) + 2 * nw * sizeof(double) + nw * 16 * sizeof(float) +
+                       (ln ? w.cols * sizeof(float) : 0);
+    if (lds > 64 * 1024) {
+        static std::unordered_set<const void *> raised;  // raised once per kernel, outside any capture
+        if (!raised.count((const void *)kfn)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised.insert((const void *)kfn);
+        }
+    }
+    for (size_t m0 = 0; m0 < m; ++m0) {  // one activation row per launch (forward_qk256's row loop, T:683-691)
         a.x = x + m0 * w.cols;
         a.y = y + m0 * out_rows;
         a.residual = fu.residual ? fu.residual + m0 * w.rows : nullptr;
-        if (left >= 4 && !a.stiles) {
-            const size_t lds = (size_t)16 * (a.nblk * 256 + 16) + (24 * 4 + 4 + kWaves * 4 * 16) * sizeof(float);
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemv_mfma<4>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            hipLaunchKernelGGL(k_gemv_mfma<4>, dim3(grid), dim3(512), lds, stream, a);
-            m0 += 4;
-        } else {
-            const size_t lds = (size_t)4 * (a.nblk * 256 + 16) + (24 + 4 + kWaves * 16) * sizeof(float);
-            hipLaunchKernelGGL(k_gemv_mfma<1>, dim3(grid), dim3(512), lds, stream, a);
-            m0 += 1;
-        }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

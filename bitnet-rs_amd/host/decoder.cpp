@@ -57,6 +57,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     ok &= dalloc(&h_, (size_t)c_.ffn) == hipSuccess;
     ok &= dalloc(&logits_, (size_t)c_.vocab) == hipSuccess;
     ok &= hipMalloc(&scratch_, 8 * (size_t)logits_wgs_) == hipSuccess;
+    ok &= hipMalloc((void **)&attn_scratch_, bitnet_hip_attention_scratch_bytes((size_t)c_.n_kv_heads, (size_t)c_.max_pos)) == hipSuccess;
     ok &= dalloc(&pos_, 1) == hipSuccess && dalloc(&n_forced_, 1) == hipSuccess && dalloc(&token_, 1) == hipSuccess;
     ok &= dalloc(&history_, (size_t)c_.max_pos + 2) == hipSuccess;
     ok &= dalloc(&rope_sin_, (size_t)c_.max_pos * half) == hipSuccess;
@@ -98,7 +99,7 @@ Decoder::~Decoder() {
             if (p) hipFree(p);
     }
     for (void *p : {(void *)embed_, (void *)final_norm_, (void *)rope_sin_, (void *)rope_cos_, (void *)x_, (void *)x2_,
-                    (void *)qkv_, (void *)att_, (void *)h_, (void *)logits_, scratch_, (void *)pos_, (void *)n_forced_,
+                    (void *)qkv_, (void *)att_, (void *)h_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
     if (stream_) hipStreamDestroy((hipStream_t)stream_);
@@ -207,7 +208,7 @@ int Decoder::step_launches(bool with_logits) {
         // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
         BCHK(bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, s));
         BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                             (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, att_, s));
+                                             (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
         // o_proj + residual (T:542, T:1073)
         BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
         // post_attention_layernorm -> gate, up -> silu(gate)*up (T:1104, T:756-781)
@@ -301,19 +302,37 @@ int Decoder::layer_trace(float *) {
     return BITNET_HIP_ERR_UNSUPPORTED;
 }
 
-int Decoder::probe_gateup(int reps, float *us_per_launch, double *bytes_per_launch) {
+// kind: 0 q|k|v, 1 attention, 2 o_proj, 3 gate|up, 4 down, 5 logits+argmax
+int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *bytes_per_launch) {
     hipStream_t s = (hipStream_t)stream_;
+    const int p0 = position();
     hipGraph_t g = nullptr;
     HCHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     int rc = 0;
+    const size_t H = c_.hidden;
+    int launches = 0;
     for (auto &L : layers_) {
-        rc = bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, stream_);
-        if (rc) break;
+        switch (kind) {
+            case 0: rc = bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, stream_); break;
+            case 1:
+                rc = bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
+                                                     (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, stream_);
+                break;
+            case 2: rc = bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, stream_); break;
+            case 3: rc = bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, stream_); break;
+            case 4: rc = bitnet_hip_gemv_fused_dev(L.down, h_, x_, 1, nullptr, 0.f, x2_, 0, stream_); break;
+            default:
+                rc = bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_,
+                                               (size_t)logits_wgs_, token_, nullptr, nullptr, nullptr, stream_);
+                break;
+        }
+        ++launches;
+        if (rc || kind > 4) break;
     }
     const hipError_t e = hipStreamEndCapture(s, &g);
     if (rc) {
         if (g) hipGraphDestroy(g);
-        return fail("probe_gateup launch");
+        return fail("probe_kernel launch");
     }
     HCHK(e);
     hipGraphExec_t ex = nullptr;
@@ -333,14 +352,26 @@ int Decoder::probe_gateup(int reps, float *us_per_launch, double *bytes_per_laun
     hipEventDestroy(e1);
     hipGraphExecDestroy(ex);
     hipGraphDestroy(g);
-    if (us_per_launch) *us_per_launch = ms * 1e3f / (float)(reps * c_.n_layers);
+    (void)p0;
+    if (us_per_launch) *us_per_launch = ms * 1e3f / (float)(reps * launches);
     if (bytes_per_launch) {
         size_t ab = 0;
-        bitnet_hip_weights_info(layers_[0].gateup, nullptr, nullptr, &ab);
-        // + activation vector in, hidden vector out, gamma (cols*4 + 4*rows)
-        *bytes_per_launch = (double)ab + 4.0 * c_.hidden * 2 + 4.0 * c_.ffn;
+        const Layer &L = layers_[0];
+        const double kv = 2.0 * c_.n_kv_heads * (double)(position() + 1) * c_.head_dim * 4;
+        switch (kind) {  // algorithmic bytes of one launch: codes + scales + vector in + vector out
+            case 0: bitnet_hip_weights_info(L.qkv, nullptr, nullptr, &ab); *bytes_per_launch = (double)ab + 8.0 * H + 4.0 * (c_.n_heads + 2 * c_.n_kv_heads) * c_.head_dim; break;
+            case 1: *bytes_per_launch = kv + 8.0 * c_.n_heads * c_.head_dim; break;
+            case 2: bitnet_hip_weights_info(L.o, nullptr, nullptr, &ab); *bytes_per_launch = (double)ab + 4.0 * c_.n_heads * c_.head_dim + 8.0 * H; break;
+            case 3: bitnet_hip_weights_info(L.gateup, nullptr, nullptr, &ab); *bytes_per_launch = (double)ab + 8.0 * H + 4.0 * c_.ffn; break;
+            case 4: bitnet_hip_weights_info(L.down, nullptr, nullptr, &ab); *bytes_per_launch = (double)ab + 4.0 * c_.ffn + 8.0 * H; break;
+            default: *bytes_per_launch = 2.0 * (double)c_.vocab * H + 8.0 * H + 4.0 * c_.vocab; break;
+        }
     }
     return 0;
+}
+
+int Decoder::probe_gateup(int reps, float *us_per_launch, double *bytes_per_launch) {
+    return probe_kernel(3, reps, us_per_launch, bytes_per_launch);
 }
 
 }  // namespace bitnet_host
@@ -396,6 +427,9 @@ int bitnet_host_last_logits(void *d, float *out) { return static_cast<Decoder *>
 int bitnet_host_last_hidden(void *d, float *out) { return static_cast<Decoder *>(d)->last_hidden(out); }
 int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch) {
     return static_cast<Decoder *>(d)->probe_gateup(reps, us_per_launch, bytes_per_launch);
+}
+int bitnet_host_probe_kernel(void *d, int kind, int reps, float *us_per_launch, double *bytes_per_launch) {
+    return static_cast<Decoder *>(d)->probe_kernel(kind, reps, us_per_launch, bytes_per_launch);
 }
 uint64_t bitnet_host_weight_bytes(void *d) { return static_cast<Decoder *>(d)->weight_bytes(); }
 }

@@ -74,6 +74,8 @@ class Decoder {
     // one graph, `reps` replays; returns the mean time per launch and the algorithmic
     // bytes one launch reads.
     int probe_gateup(int reps, float *us_per_launch, double *bytes_per_launch);
+    // Same for any kernel of the step: kind 0 q|k|v, 1 attention, 2 o_proj, 3 gate|up, 4 down, 5 logits.
+    int probe_kernel(int kind, int reps, float *us_per_launch, double *bytes_per_launch);
     size_t weight_bytes() const { return weight_bytes_; }  // algorithmic bytes of all I2_S matrices
     void *stream() const { return stream_; }
 
@@ -96,6 +98,7 @@ class Decoder {
     float *rope_sin_ = nullptr, *rope_cos_ = nullptr;
     float *x_ = nullptr, *x2_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *h_ = nullptr, *logits_ = nullptr;
     void *scratch_ = nullptr;
+    float *attn_scratch_ = nullptr;
     int32_t *pos_ = nullptr, *n_forced_ = nullptr, *history_ = nullptr, *token_ = nullptr;
     int host_forced_ = 0;
     size_t weight_bytes_ = 0;
@@ -129,5 +132,6 @@ int bitnet_host_history(void *d, int32_t *out, int n);
 int bitnet_host_last_logits(void *d, float *out);
 int bitnet_host_last_hidden(void *d, float *out);
 int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch);
+int bitnet_host_probe_kernel(void *d, int kind, int reps, float *us_per_launch, double *bytes_per_launch);
 uint64_t bitnet_host_weight_bytes(void *d);
 }

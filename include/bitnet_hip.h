@@ -225,7 +225,10 @@ int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream);
 int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_dev,
                                     const float *rope_cos_dev, float *kcache_dev, float *vcache_dev,
                                     size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
-                                    const int32_t *pos_dev, float *out_dev, void *stream);
+                                    const int32_t *pos_dev, float *scratch_dev, float *out_dev,
+                                    void *stream);
+/* bytes of scratch_dev the call above needs (per-chunk softmax partials) */
+size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos);
 /* TransformerModel::logits, tied embeddings (T:1599-1630): logits = LN(x) . E^T, E the f16
  * table [vocab, hidden], f32 accumulate; gamma_dev == NULL skips the final norm (T:1589).
  * scratch_dev: >= 8 * n_workgroups bytes (argmax partials); token_dev (nullable) receives

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--layers", type=int, default=30)
     ap.add_argument("--warm-ms", type=float, default=0)
     ap.add_argument("--replays", type=int, default=3)
+    ap.add_argument("--fused", action="store_true")
     args = ap.parse_args()
     hip = pkg.HipLib(pkg.LIB_PATH.replace(".so", "_diag.so"))
     hip.init(0)
@@ -36,21 +37,39 @@ def main():
     rows, cols = SHAPES[args.shape]
     stride = cols // 256 * 64
     rng = np.random.default_rng(0)
-    handles = [hip.weights_upload_qk256(rng.integers(0, 256, rows * stride, dtype=np.uint8), rows, cols, stride) for _ in range(args.layers)]
+    def mk():
+        return hip.weights_upload_qk256(rng.integers(0, 256, rows * stride, dtype=np.uint8), rows, cols, stride)
+
+    if args.fused:  # the decode step's LayerNorm -> gate|up -> silu*mul launch
+        handles = []
+        for _ in range(args.layers):
+            a, b = mk(), mk()
+            handles.append(hip.weights_concat([a, b], interleave16=True))
+            hip.weights_free(a)
+            hip.weights_free(b)
+    else:
+        handles = [mk() for _ in range(args.layers)]
+    gamma = torch.full((cols,), 0.0125, device="cuda")
     hip.set_kernel({"mfma": pkg.KERNEL_MFMA, "mfma_tiled": pkg.KERNEL_MFMA_TILED}[args.kernel])
     x = torch.randn(cols, device="cuda")
-    y = torch.empty(rows, device="cuda")
+    y = torch.empty(2 * rows, device="cuda")
     stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
     cs = torch.cuda.current_stream().cuda_stream
-    for h in handles:  # warm (builds tiles)
-        hip.gemv_dev(h, x, y, cs)
+    def launch(h, st):
+        if args.fused:
+            hip.gemv_fused_dev(h, x, y, 1, ln_gamma=gamma, ln_eps=1e-5, flags=1, stream=st)
+        else:
+            hip.gemv_dev(h, x, y, st)
+
+    for h in handles:  # warm
+        launch(h, cs)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
         s = torch.cuda.current_stream().cuda_stream
         for i, h in enumerate(handles):
             hip.c.bitnet_hip_debug_set_stamps(C.c_void_p(stamps.data_ptr() if i == len(handles) - 1 else 0))
-            hip.gemv_dev(h, x, y, s)
+            launch(h, s)
     if args.warm_ms > 0:  # hold the GPU busy so DPM raises the shader clock
         a = torch.randn(8192, 8192, device="cuda")
         t_end = __import__("time").time() + args.warm_ms / 1e3
