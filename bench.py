@@ -58,6 +58,21 @@ def build_model(pkg, synth, workload: str, layers_override: int | None):
     return cfg, dec, keep
 
 
+def load_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass
+    (profiles/traffic_<workload>.json, written by tools/profile_round.sh: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on FETCH_SIZE).
+    PMC counters cannot be read from inside this process, so the figure is the measured one
+    of the profiled build; null when no such file is committed for the workload."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return int(t["hbm_fetch_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def cpu_baseline(cfg, synth):
     """The reference's live CPU decode path (QK256 AVX2 GEMV per projection,
     Q/i2s_qk256_avx2.rs:254-295, single-threaded like the reference's row loop
@@ -171,7 +186,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        "traffic": load_traffic(args.workload),
         "bytes_per_launch": int(abytes),
         "us_per_launch": round(us, 3),
     }

@@ -1,0 +1,75 @@
+"""Summarise one tools/profile_round.sh run: per-kernel time (rocprofv3 --kernel-trace) and
+HBM traffic per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes).
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half of the
+bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so fetch bytes =
+2 * FETCH_SIZE * 1024; WRITE_SIZE reads exactly for 16-B-per-lane streaming stores
+(bytes = WRITE_SIZE * 1024).  Other access widths are uncalibrated.
+
+    python tools/profile_summary.py gpurun_out/prof_r01 r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"(?:bitnet_hip::)?([A-Za-z0-9_]+(?:<[^(]*>)?)", name)
+    if name.startswith("_ZN10bitnet_hip"):
+        m2 = re.match(r"_ZN10bitnet_hip\d+([a-z_0-9A-Z]+?)(?:I|E)", name)
+        return m2.group(1) if m2 else name[:40]
+    return (m.group(1) if m else name)[:60]
+
+
+def main():
+    out_dir, tag = sys.argv[1], sys.argv[2]
+    trace = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    k = collections.defaultdict(list)
+    grids = collections.defaultdict(set)
+    for f in trace:
+        for r in csv.DictReader(open(f)):
+            key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
+            k[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    pmc = {}
+    for cname, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0 * 1024.0), ("WRITE_SIZE", "pmc_write", 1024.0)):
+        d = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else 1
+                key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // max(1, wg))
+                d[key].append(float(r["Counter_Value"]) * mult)
+        pmc[cname] = d
+    rows = []
+    total = sum(sum(v) for v in k.values())
+    for key, v in sorted(k.items(), key=lambda kv: -sum(kv[1])):
+        v.sort()
+        fetch = pmc["FETCH_SIZE"].get(key)
+        write = pmc["WRITE_SIZE"].get(key)
+        rows.append({
+            "kernel": key[0], "workgroups": key[1], "calls": len(v), "total_ms": round(sum(v) / 1e6, 3),
+            "pct": round(100.0 * sum(v) / total, 2), "avg_us": round(sum(v) / len(v) / 1e3, 3), "min_us": round(v[0] / 1e3, 3),
+            "med_us": round(v[len(v) // 2] / 1e3, 3), "max_us": round(v[-1] / 1e3, 3),
+            "hbm_fetch_bytes_per_launch": round(sum(fetch) / len(fetch)) if fetch else None,
+            "hbm_write_bytes_per_launch": round(sum(write) / len(write)) if write else None,
+        })
+    with open(os.path.join(out_dir, "summary.json"), "w") as f:
+        json.dump({"tag": tag, "kernels": rows}, f, indent=1)
+    with open(os.path.join(out_dir, "summary.md"), "w") as f:
+        f.write(f"# rocprofv3 summary {tag}\n\n")
+        f.write("Times: `rocprofv3 --kernel-trace --stats`; bytes: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, ")
+        f.write("fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024.\n\n")
+        f.write("| kernel | WGs | calls | total ms | % | avg us | min | med | max | HBM fetch B/launch | HBM write B/launch |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in rows:
+            f.write("| {kernel} | {workgroups} | {calls} | {total_ms} | {pct} | {avg_us} | {min_us} | {med_us} | {max_us} | {hbm_fetch_bytes_per_launch} | {hbm_write_bytes_per_launch} |\n".format(**r))
+    print(open(os.path.join(out_dir, "summary.md")).read())
+
+
+if __name__ == "__main__":
+    main()
