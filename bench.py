@@ -127,20 +127,15 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback path)"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
-
     pkg = importlib.import_module("bitnet-rs_amd")
     synth = importlib.import_module("bitnet-rs_amd.synth")
+    dist_ = importlib.import_module("bitnet-rs_amd.dist")
+    r = dist_.init("nccl")  # RCCL; one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torchrun)
+    world, rank, local_rank = r.world, r.rank, r.local_rank
+    torch.cuda.set_device(local_rank)
+    n_gpus = world
     if not os.path.exists(pkg.LIB_PATH) or not os.path.exists(pkg.HOST_LIB_PATH):
         pkg.build()
     hip = pkg.load()
@@ -156,22 +151,15 @@ def main():
     dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
     dec.run(args.warmup, with_logits=True, use_graph=use_graph)      # W untimed warm-up steps
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    ev = {}
 
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = dec.run(args.steps, with_logits=True, use_graph=use_graph)  # exactly K timed steps (stream-synchronised inside)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = n_gpus * args.steps / elapsed
+    def timed():
+        ev["ms"] = dec.run(args.steps, with_logits=True, use_graph=use_graph)  # exactly K timed steps (stream-synchronised inside)
+
+    # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (bitnet-rs_amd/dist.py)
+    elapsed = dist_.timed_region(r, timed)
+    ev_ms = ev["ms"]
+    value = dist_.aggregate_throughput(r, args.steps, elapsed)
     tokens = dec.history(PROMPT_LEN + 1 + args.warmup + args.steps)
 
     # dominant kernel: the fused gate|up GEMV (largest byte stream of a layer).  Every
@@ -234,8 +222,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
         print(json.dumps(out), flush=True)
     dec.close()
-    if world > 1:
-        dist.destroy_process_group()
+    dist_.finalize(r)
 
 
 if __name__ == "__main__":
