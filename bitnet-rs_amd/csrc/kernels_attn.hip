@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     const int group = n_heads / n_kv, half = kD / 2;
     const bool owns_new = pos >= j0 && pos < j0 + kAttnChunk;
     const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
+    float *kt = kcache + (size_t)kvh * kD * max_pos;  // [D][max_pos]
+    float *vc = vcache + (size_t)kvh * max_pos * kD;  // [max_pos][D]
+    // ---- every cache load of this thread is issued up front (none depends on q): the K
+    //      slice for the score pass (lane = position) and the V column for the P.V pass
+    //      (lane = dim); clamped addresses, masked later, so the loads are unconditional ----
+    float kv[32], vv[kAttnChunk / 2];
+    {
+        const int j = j0 + lane, jc = j < pos ? j : (pos > 0 ? pos - 1 : 0);
+        const float *kp = kt + (size_t)(32 * wave) * max_pos + jc;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) kv[i] = kp[(size_t)i * max_pos];
+        // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions jj = hp, hp+2, ...
+        const int d = tid & 127, hp = tid >> 7;
+#pragma unroll
+        for (int i = 0; i < kAttnChunk / 2; ++i) {
+            const int jj = j0 + 2 * i + hp, jcl = jj < pos ? jj : (pos > 0 ? pos - 1 : 0);
+            vv[i] = vc[(size_t)jcl * kD + d];
+        }
+    }
     // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------
     {
         const int g = tid >> 6, j = tid & 63;  // 4 heads x 64 rotation pairs = 256 threads
@@ -72,8 +91,6 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         qs[g * kD + j] = a;
         qs[g * kD + half + j] = b;
     }
-    float *kt = kcache + (size_t)kvh * kD * max_pos;  // [D][max_pos]
-    float *vc = vcache + (size_t)kvh * max_pos * kD;  // [max_pos][D]
     if (owns_new) {
         if (tid < half) {
             const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
@@ -93,10 +110,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
     {
         const int j = j0 + lane;
-        float kv[32];
-        const float *kp = kt + (size_t)(32 * wave) * max_pos + j;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = (j < pos) ? kp[(size_t)i * max_pos] : (j == pos ? kn[32 * wave + i] : 0.0f);
+        for (int i = 0; i < 32; ++i) kv[i] = (j < pos) ? kv[i] : (j == pos ? kn[32 * wave + i] : 0.0f);
         float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 32; i += 4) {
@@ -126,22 +141,27 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         sc[g][lane] = e;
     }
     __syncthreads();
-    // ---- un-normalised P.V: thread = (dim d, head pair); 64 independent V loads --------------
+    // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
     {
         const int d = tid & 127, hp = tid >> 7;
         const int cnt = t_k - j0 < kAttnChunk ? t_k - j0 : kAttnChunk;
-        float a0 = 0.0f, a1 = 0.0f;
-        const float *vp = vc + (size_t)j0 * kD + d;
-#pragma unroll 16
-        for (int jj = 0; jj < kAttnChunk; ++jj) {
-            float v = 0.0f;
-            if (jj < cnt) v = (j0 + jj == pos) ? vn[d] : vp[(size_t)jj * kD];
-            a0 += sc[2 * hp][jj] * v;
-            a1 += sc[2 * hp + 1][jj] * v;
+        float a[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < kAttnChunk / 2; ++i) {
+            const int jj = 2 * i + hp;
+            const float v = jj < cnt ? (j0 + jj == pos ? vn[d] : vv[i]) : 0.0f;
+#pragma unroll
+            for (int g = 0; g < kMaxGroup; ++g) a[g] += sc[g][jj] * v;
         }
-        rec[2 * kMaxGroup + (2 * hp) * kD + d] = a0;
-        rec[2 * kMaxGroup + (2 * hp + 1) * kD + d] = a1;
+        // the two position parities meet through LDS (reuse the score partials buffer)
+        float *red = &partial[0][0][0];  // [2][kMaxGroup][kD] = 1024 floats = sizeof(partial)
+        __syncthreads();                 // everyone is done reading partial[][][]
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) red[(hp * kMaxGroup + g) * kD + d] = a[g];
+        __syncthreads();
+#pragma unroll
+        for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = red[g * kD + d] + red[(kMaxGroup + g) * kD + d];
     }
     if (lane == 0) {
         rec[wave] = m_c;
