@@ -74,6 +74,8 @@ class DeviceInfo(C.Structure):
 
 
 def _np(a, dtype):
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(a, dtype=np.uint8)
     return np.ascontiguousarray(a, dtype=dtype)
 
 
@@ -106,6 +108,8 @@ class HipLib:
         L.bitnet_hip_dequant_i2s.argtypes = [_u8p, _sz, _sz, _sz, C.c_int, C.c_float, C.c_int, _f32p, _sz]
         L.bitnet_hip_weights_upload_qk256.argtypes = [_u8p, _sz, _sz, _sz, _sz, C.POINTER(C.c_uint64)]
         L.bitnet_hip_weights_upload_i2s.argtypes = [_u8p, _sz, _f32p, _sz, _sz, _sz, _sz, C.POINTER(C.c_uint64)]
+        L.bitnet_hip_weights_upload_coded.argtypes = [_u8p, _sz, _f32p, _sz, _sz, _sz, _sz, _i8p, C.POINTER(C.c_uint64)]
+        L.bitnet_hip_weights_upload_inline_f16.argtypes = [_u8p, _sz, _sz, _sz, _i8p, C.c_int, C.POINTER(C.c_uint64)]
         L.bitnet_hip_weights_free.argtypes = [C.c_uint64]
         L.bitnet_hip_weights_info.argtypes = [C.c_uint64, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]
         L.bitnet_hip_gemv_dev.argtypes = [C.c_uint64, _vp, _vp, _vp]
@@ -231,6 +235,18 @@ class HipLib:
         self._check(self.c.bitnet_hip_weights_upload_i2s(wq.ctypes.data_as(_u8p), wq.size, s.ctypes.data_as(_f32p), s.size, n, k, block_size, C.byref(h)))
         return h.value
 
+    def weights_upload_coded(self, w, scales, n, k, block_size, code_map) -> int:
+        wq, s, cm = _np(w, np.uint8), _np(scales, np.float32), _np(code_map, np.int8)
+        h = C.c_uint64(0)
+        self._check(self.c.bitnet_hip_weights_upload_coded(wq.ctypes.data_as(_u8p), wq.size, s.ctypes.data_as(_f32p), s.size, n, k, block_size, cm.ctypes.data_as(_i8p), C.byref(h)))
+        return h.value
+
+    def weights_upload_inline_f16(self, blocks, n, k, code_map, scale_mode: int = 0) -> int:
+        b, cm = _np(blocks, np.uint8), _np(code_map, np.int8)
+        h = C.c_uint64(0)
+        self._check(self.c.bitnet_hip_weights_upload_inline_f16(b.ctypes.data_as(_u8p), b.size, n, k, cm.ctypes.data_as(_i8p), scale_mode, C.byref(h)))
+        return h.value
+
     def weights_free(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_free(h))
 
@@ -315,6 +331,91 @@ class HostConfig(C.Structure):
     ]
 
 
+FLAVORS = ("BitNet32F16", "Split32WithSibling", "GgmlQk256NoScale")
+
+
+class GgufFile:
+    """ctypes view of the C++ GGUF reader (bitnet-rs_amd/host/gguf.cpp): header / KV / tensor
+    records, sizes from offsets, I2_S flavour detection.  Pure host code: usable without a GPU."""
+
+    def __init__(self, path: str | None = None, data: bytes | None = None, lib_path: str = HOST_LIB_PATH):
+        if not os.path.exists(lib_path):
+            raise FileNotFoundError(f"{lib_path} not found: build it with __graft_entry__.build()")
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not found: build it with __graft_entry__.build()")
+        C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L = self.c = C.CDLL(lib_path)
+        L.bitnet_host_gguf_open.restype = C.c_void_p
+        L.bitnet_host_gguf_open.argtypes = [C.c_char_p]
+        L.bitnet_host_gguf_from_memory.restype = C.c_void_p
+        L.bitnet_host_gguf_from_memory.argtypes = [_u8p, _sz]
+        L.bitnet_host_gguf_close.argtypes = [C.c_void_p]
+        L.bitnet_host_gguf_error.restype = C.c_char_p
+        L.bitnet_host_gguf_tensor_count.restype = C.c_int64
+        L.bitnet_host_gguf_tensor_count.argtypes = [C.c_void_p]
+        L.bitnet_host_gguf_tensor_info.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.bitnet_host_gguf_data_start.restype = C.c_uint64
+        L.bitnet_host_gguf_data_start.argtypes = [C.c_void_p]
+        L.bitnet_host_gguf_config.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+        L.bitnet_host_gguf_detect_i2s_flavor.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        L.bitnet_host_gguf_loader_is_qk256.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64]
+        self.h = None
+        if path is not None:
+            self.h = L.bitnet_host_gguf_open(path.encode())
+        elif data is not None:
+            self._buf = np.frombuffer(data, np.uint8).copy()  # must outlive the reader
+            self.h = L.bitnet_host_gguf_from_memory(self._buf.ctypes.data_as(_u8p), self._buf.size)
+        if (path is not None or data is not None) and not self.h:
+            raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error() or "GGUF parse failed")
+
+    def error(self) -> str:
+        e = self.c.bitnet_host_gguf_error()
+        return e.decode(errors="replace") if e else ""
+
+    def close(self) -> None:
+        if self.h:
+            self.c.bitnet_host_gguf_close(self.h)
+            self.h = None
+
+    @property
+    def data_start(self) -> int:
+        return int(self.c.bitnet_host_gguf_data_start(self.h))
+
+    def tensors(self) -> list:
+        out = []
+        for i in range(self.c.bitnet_host_gguf_tensor_count(self.h)):
+            name = C.create_string_buffer(512)
+            shape = (C.c_uint64 * 8)()
+            nd, ty, off, size = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+            rc = self.c.bitnet_host_gguf_tensor_info(self.h, i, name, 512, shape, C.byref(nd), C.byref(ty), C.byref(off), C.byref(size))
+            if rc != 0:
+                raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error())
+            out.append({"name": name.value.decode(), "shape": tuple(int(shape[j]) for j in range(nd.value)), "type": ty.value,
+                        "offset": off.value, "size": size.value})
+        return out
+
+    def config(self) -> dict:
+        cfg, f = (C.c_uint64 * 6)(), (C.c_float * 2)()
+        if self.c.bitnet_host_gguf_config(self.h, cfg, f) != 0:
+            raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error())
+        keys = ("vocab", "hidden", "n_layers", "n_heads", "n_kv_heads", "ffn")
+        d = {k: int(cfg[i]) for i, k in enumerate(keys)}
+        d["rope_theta"] = None if f[0] != f[0] else float(f[0])
+        d["eps"] = None if f[1] != f[1] else float(f[1])
+        return d
+
+    def detect_i2s_flavor(self, available: int, nelems: int, has_scale_sibling: bool, strict: bool = False) -> str:
+        rc = self.c.bitnet_host_gguf_detect_i2s_flavor(available, nelems, int(has_scale_sibling), int(strict))
+        if rc < 0:
+            raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error())
+        return FLAVORS[rc]
+
+    def loader_is_qk256(self, shape, available: int) -> bool:
+        sh = (C.c_uint64 * len(shape))(*shape)
+        return bool(self.c.bitnet_host_gguf_loader_is_qk256(sh, len(shape), available))
+
+
 class HostDecoder:
     """ctypes view of the C++ Decoder (mirror of the reference's Rust-side
     TransformerModel / KVCache / greedy loop).  No arithmetic here."""
@@ -363,6 +464,10 @@ class HostDecoder:
         if self.h:
             self.c.bitnet_host_destroy(self.h)
             self.h = None
+
+    def load_gguf(self, gguf: "GgufFile") -> None:
+        self.c.bitnet_host_load_gguf.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.c.bitnet_host_load_gguf(self.h, gguf.h))
 
     def set_layer_qk256(self, layer: int, w: dict) -> None:
         a = [_np(w["attn_norm"], np.float32), _np(w["ffn_norm"], np.float32)] + [_np(w[k], np.uint8) for k in ("q", "k", "v", "o", "gate", "up", "down")]

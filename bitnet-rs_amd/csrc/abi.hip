@@ -3,6 +3,7 @@
 // Argument validation mirrors the reference function each symbol replaces (cited in
 // the header); kernels live in kernels_*.hip.  No CPU fallback exists here: every
 // compute path needs a HIP device.
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -236,9 +237,11 @@ int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_
     BH_GUARD_END
 }
 
-int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, const float *scales,
-                                  size_t scales_len, size_t n, size_t k, size_t block_size,
-                                  bitnet_hip_weights_t *out) {
+}  // extern "C"
+
+// 2-bit coded matrix [n, ceil(k/4)] + f32 scale per (row, block) with any 4-entry code map.
+static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float *scales, size_t scales_len, size_t n,
+                        size_t k, size_t block_size, uint32_t lut, bitnet_hip_weights_t *out) {
     BH_GUARD_BEGIN
     if (!weights_packed || !scales || !out)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_i2s");
@@ -260,7 +263,7 @@ int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, c
     w->row_stride_bytes = packed_k;
     w->block_size = block_size;
     w->nblk = nblk;
-    w->lut = LUT_TERNARY;
+    w->lut = lut;
     w->algorithmic_bytes = packed_k * n + 4 * n * nblk;
     w->device = g_device;
     if (hipMalloc((void **)&w->codes, packed_k * n + 16) != hipSuccess ||
@@ -278,6 +281,52 @@ int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, c
         return set_error(BITNET_HIP_ERR_GPU, "re-tiling I2_S codes for the MFMA kernel failed");
     }
     return register_weights(w, out);
+    BH_GUARD_END
+}
+
+extern "C" {
+
+int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                  size_t scales_len, size_t n, size_t k, size_t block_size,
+                                  bitnet_hip_weights_t *out) {
+    return upload_coded(weights_packed, w_len, scales, scales_len, n, k, block_size, LUT_TERNARY, out);
+}
+
+int bitnet_hip_weights_upload_coded(const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                    size_t scales_len, size_t n, size_t k, size_t block_size, const int8_t *code_map,
+                                    bitnet_hip_weights_t *out) {
+    if (!code_map) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_coded");
+    return upload_coded(weights_packed, w_len, scales, scales_len, n, k, block_size,
+                        pack_lut(code_map[0], code_map[1], code_map[2], code_map[3]), out);
+}
+
+int bitnet_hip_weights_upload_inline_f16(const uint8_t *blocks, size_t len, size_t n, size_t k, const int8_t *code_map,
+                                         int scale_mode, bitnet_hip_weights_t *out) {
+    BH_GUARD_BEGIN
+    if (!blocks || !code_map || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_inline_f16");
+    if (n == 0 || k == 0 || k % 32 != 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "inline f16 blocks need k %% 32 == 0 and n, k > 0: n=%zu, k=%zu", n, k);
+    const size_t nb = n * (k / 32);
+    if (len < nb * 10)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "blocks too small: expected %zu, got %zu", nb * 10, len);
+    std::vector<uint8_t> codes(nb * 8);
+    std::vector<float> scales(nb);
+    for (size_t b = 0; b < nb; ++b) {
+        memcpy(&codes[b * 8], blocks + b * 10, 8);
+        uint16_t bits;
+        memcpy(&bits, blocks + b * 10 + 8, 2);
+        _Float16 h;
+        memcpy(&h, &bits, 2);
+        float s = (float)h;
+        if (scale_mode == 1) {  // M/quant/i2s.rs:84-101
+            s = fabsf(s);
+            if (!std::isnan(s)) s = fminf(fmaxf(s, 1e-3f), 1e3f);  // f32::clamp keeps NaN
+        }
+        scales[b] = s;
+    }
+    return upload_coded(codes.data(), codes.size(), scales.data(), scales.size(), n, k, 32,
+                        pack_lut(code_map[0], code_map[1], code_map[2], code_map[3]), out);
     BH_GUARD_END
 }
 

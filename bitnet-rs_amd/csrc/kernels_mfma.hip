@@ -58,7 +58,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 4;   // weight tiles (1 KiB each) a wave keeps in flight
 constexpr int kNVMAX = 4;  // float4 LayerNorm-statistics vectors per thread (512 threads): K <= 8192
-constexpr int kWaves = 8;  // waves per workgroup (kernel template NW: 8, or 16 for many-tile launches)
 
 struct MfmaArgs {
     const uint8_t *tiles;  // [n_tiles][nblk][64 lanes][16 B], fields transposed (k_retile)

@@ -160,6 +160,41 @@ int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
     return 0;
 }
 
+int Decoder::set_layer_specs(int layer, const float *attn_norm, const float *ffn_norm, const ProjSpec p[7]) {
+    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    Layer &L = layers_[(size_t)layer];
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
+    if (p[0].qk256 != p[1].qk256 || p[0].qk256 != p[2].qk256 || p[4].qk256 != p[5].qk256) {
+        err_ = "q|k|v (and gate|up) must share one I2_S flavour to be fused";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    HCHK(hipMemcpy(L.attn_norm, attn_norm, H * 4, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(L.ffn_norm, ffn_norm, H * 4, hipMemcpyHostToDevice));
+    bitnet_hip_weights_t h[7] = {0};
+    for (int i = 0; i < 7; ++i) {
+        if (p[i].qk256) {
+            const size_t stride = (k[i] + 255) / 256 * 64;
+            BCHK(bitnet_hip_weights_upload_qk256(p[i].bytes, p[i].len, n[i], k[i], stride, &h[i]));
+        } else {
+            BCHK(bitnet_hip_weights_upload_coded(p[i].bytes, p[i].len, p[i].scales, p[i].n_scales, n[i], k[i], p[i].block,
+                                                 p[i].code_map, &h[i]));
+        }
+    }
+    const bitnet_hip_weights_t qkv[3] = {h[0], h[1], h[2]}, gu[2] = {h[4], h[5]};
+    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
+    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
+    L.o = h[3];
+    L.down = h[6];
+    for (int i : {0, 1, 2, 4, 5}) bitnet_hip_weights_free(h[i]);
+    for (bitnet_hip_weights_t hh : {L.qkv, L.o, L.gateup, L.down}) {
+        size_t ab = 0;
+        bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
+        weight_bytes_ += ab;
+    }
+    return 0;
+}
+
 int Decoder::set_globals(const uint16_t *embed_f16, const float *final_norm) {
     const size_t n = (size_t)c_.vocab * c_.hidden * 2;
     if (!embed_) HCHK(hipMalloc(&embed_, n));

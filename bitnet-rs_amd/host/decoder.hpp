@@ -42,6 +42,17 @@ struct LayerWeightsI2s {
     size_t block_size;
 };
 
+// One projection as a loader hands it over: QK256 bytes, or 2-bit codes + f32 block scales
+// with an explicit code map (bitnet_hip_weights_upload_coded).
+struct ProjSpec {
+    bool qk256 = true;
+    const uint8_t *bytes = nullptr;
+    size_t len = 0;
+    const float *scales = nullptr;  // coded only: [rows, cols / block]
+    size_t n_scales = 0, block = 32;
+    int8_t code_map[4] = {-2, -1, 0, 1};
+};
+
 class Decoder {
   public:
     explicit Decoder(const Config &cfg);
@@ -51,10 +62,13 @@ class Decoder {
 
     const Config &config() const { return c_; }
     const std::string &error() const { return err_; }
+    void set_error(const std::string &e) { err_ = e; }
 
     // weights (uploaded once; fused q|k|v and interleaved gate/up handles are built here)
     int set_layer_qk256(int layer, const LayerWeightsQk256 &w);
     int set_layer_i2s(int layer, const LayerWeightsI2s &w);
+    // q,k,v,o,gate,up,down in any mix of storage forms (q|k|v and gate|up must agree)
+    int set_layer_specs(int layer, const float *attn_norm, const float *ffn_norm, const ProjSpec p[7]);
     int set_globals(const uint16_t *embed_f16, const float *final_norm);
 
     // KVCache::clear (T:1251-1255) + token history

@@ -165,6 +165,18 @@ int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_
 int bitnet_hip_weights_upload_i2s(const uint8_t *weights_packed, size_t w_len, const float *scales,
                                   size_t scales_len, size_t n, size_t k, size_t block_size,
                                   bitnet_hip_weights_t *out);
+/* Same storage with an explicit 4-entry code map (value of code 0..3), e.g. {-2,-1,0,+1}
+ * x f32 block scale = I2SQuantizer::dequantize_tensor, the form the GGUF loader gives the
+ * 32-element flavours (Q/utils.rs:76-91, Q/i2s.rs:181-237, M/gguf_simple.rs:1260-1285). */
+int bitnet_hip_weights_upload_coded(const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                    size_t scales_len, size_t n, size_t k, size_t block_size,
+                                    const int8_t *code_map, bitnet_hip_weights_t *out);
+/* BitNet32-F16 on-disk blocks: per 32 elements 8 code bytes + 2 bytes LE f16 scale, blocks
+ * running row-major over [n, k] (k % 32 == 0).  scale_mode 0: scale = f16 as stored
+ * (M/gguf_simple.rs:1217-1233); scale_mode 1: scale = clamp(|f16|, 1e-3, 1e3)
+ * (M/quant/i2s.rs:66-100, Sym map, k = 1). */
+int bitnet_hip_weights_upload_inline_f16(const uint8_t *blocks, size_t len, size_t n, size_t k,
+                                         const int8_t *code_map, int scale_mode, bitnet_hip_weights_t *out);
 int bitnet_hip_weights_free(bitnet_hip_weights_t w);
 /* rows (n), cols (k), algorithmic bytes one GEMV reads from this handle
  * (code bytes + scale bytes). */

@@ -345,11 +345,18 @@ class OracleModel:
         mc = ModelCfg(**{k: (float(v) if k in ("eps", "rope_theta") else int(v)) for k, v in cfg.asdict().items()})
         self.m = L.bo_model_create(C.byref(mc), n_threads)
         self._keep = []
+        L.bo_model_set_layer_dense.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.POINTER(_f32p)]
         for i, w in enumerate(layers):
             a = [np.ascontiguousarray(w["attn_norm"], np.float32), np.ascontiguousarray(w["ffn_norm"], np.float32)]
-            a += [np.ascontiguousarray(w[k], np.uint8) for k in ("q", "k", "v", "o", "gate", "up", "down")]
-            self._keep.append(a)
-            rc = L.bo_model_set_layer(self.m, i, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), *[x.ctypes.data_as(_u8p) for x in a[2:]])
+            if w.get("dense"):  # projections as dense f32 [out, in] (loader-dequantised flavours)
+                a += [np.ascontiguousarray(w[k], np.float32) for k in ("q", "k", "v", "o", "gate", "up", "down")]
+                self._keep.append(a)
+                wp = (_f32p * 7)(*[x.ctypes.data_as(_f32p) for x in a[2:]])
+                rc = L.bo_model_set_layer_dense(self.m, i, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), wp)
+            else:
+                a += [np.ascontiguousarray(w[k], np.uint8) for k in ("q", "k", "v", "o", "gate", "up", "down")]
+                self._keep.append(a)
+                rc = L.bo_model_set_layer(self.m, i, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), *[x.ctypes.data_as(_u8p) for x in a[2:]])
             assert rc == 0
         e, f = np.ascontiguousarray(glob["embed_f16"], np.uint16), np.ascontiguousarray(glob["final_norm"], np.float32)
         self._keep.append((e, f))

@@ -31,6 +31,10 @@
 typedef struct {
     const float *attn_norm, *ffn_norm;
     const uint8_t *q, *k, *v, *o, *gate, *up, *down; /* QK256 bytes, [out, ceil(in/256)*64] */
+    /* dense f32 [out, in] per projection (q,k,v,o,gate,up,down) when the loader dequantised
+     * the tensor at load time (32-element I2_S flavours, M/gguf_simple.rs:1260-1285; then the
+     * plain candle Linear path T:546-588) */
+    const float *dense[7];
 } bo_layer;
 
 typedef struct {
@@ -182,6 +186,17 @@ int bo_model_set_layer(void *mp, int layer, const float *attn_norm, const float 
     return 0;
 }
 
+int bo_model_set_layer_dense(void *mp, int layer, const float *attn_norm, const float *ffn_norm,
+                             const float *const *w7) {
+    bo_model *m = (bo_model *)mp;
+    if (layer < 0 || layer >= m->cfg.n_layers) return 1;
+    bo_layer *L = &m->layers[layer];
+    L->attn_norm = attn_norm;
+    L->ffn_norm = ffn_norm;
+    for (int i = 0; i < 7; ++i) L->dense[i] = w7[i];
+    return 0;
+}
+
 void bo_model_set_globals(void *mp, const uint16_t *embed_f16, const float *final_norm) {
     bo_model *m = (bo_model *)mp;
     m->embed_f16 = embed_f16;
@@ -208,7 +223,17 @@ int bo_kv_len(void *p) { return ((bo_kv *)p)->seq_len; }
 
 /* forward_qk256 (T:589-702): y = gemv_qk256(W, x) -- the reference dispatches to
  * AVX2 when present (Q/i2s_qk256.rs:355-368). */
-static int proj(const bo_model *m, const uint8_t *w, const float *x, float *y, int rows, int cols) {
+static int proj(const bo_model *m, const bo_layer *L, int which, const uint8_t *w, const float *x, float *y, int rows,
+                int cols) {
+    if (L->dense[which]) { /* x . W^T, one f32 dot product per output */
+        const float *W = L->dense[which];
+        for (int r = 0; r < rows; ++r) {
+            float acc = 0.0f;
+            for (int c = 0; c < cols; ++c) acc += x[c] * W[(size_t)r * cols + c];
+            y[r] = acc;
+        }
+        return 0;
+    }
     size_t stride = (size_t)((cols + 255) / 256) * 64;
     char err[BO_ERRLEN];
     if (bo_have_avx2() && m->n_threads > 1)
@@ -282,9 +307,9 @@ int bo_model_step(void *mp, void *kvp, int token, float *hidden_out, float *logi
     for (int l = 0; l < c->n_layers && !rc; ++l) {
         const bo_layer *L = &m->layers[l];
         bo_layernorm(x, L->attn_norm, c->eps, H, xn);
-        rc |= proj(m, L->q, xn, q, NH * D, H);
-        rc |= proj(m, L->k, xn, kx, NKV * D, H);
-        rc |= proj(m, L->v, xn, vx, NKV * D, H);
+        rc |= proj(m, L, 0, L->q, xn, q, NH * D, H);
+        rc |= proj(m, L, 1, L->k, xn, kx, NKV * D, H);
+        rc |= proj(m, L, 2, L->v, xn, vx, NKV * D, H);
         for (int h = 0; h < NH; ++h) bo_rope_apply(q + (size_t)h * D, D, sin_row, cos_row);
         for (int h = 0; h < NKV; ++h) bo_rope_apply(kx + (size_t)h * D, D, sin_row, cos_row);
         float *kc = kv->k + (size_t)l * layer_stride, *vc = kv->v + (size_t)l * layer_stride;
@@ -293,13 +318,13 @@ int bo_model_step(void *mp, void *kvp, int token, float *hidden_out, float *logi
             memcpy(vc + ((size_t)h * c->max_pos + pos) * D, vx + (size_t)h * D, sizeof(float) * (size_t)D);
         }
         bo_attention_decode(q, kc, vc, NH, NKV, D, c->max_pos, pos + 1, att);
-        rc |= proj(m, L->o, att, tmp, H, NH * D);
+        rc |= proj(m, L, 3, L->o, att, tmp, H, NH * D);
         for (int i = 0; i < H; ++i) x[i] = tmp[i] + x[i]; /* x + residual T:1073 */
         bo_layernorm(x, L->ffn_norm, c->eps, H, xn);
-        rc |= proj(m, L->gate, xn, gate, F, H);
-        rc |= proj(m, L->up, xn, up, F, H);
+        rc |= proj(m, L, 4, L->gate, xn, gate, F, H);
+        rc |= proj(m, L, 5, L->up, xn, up, F, H);
         for (int i = 0; i < F; ++i) gate[i] = bo_silu(gate[i]) * up[i];
-        rc |= proj(m, L->down, gate, tmp, H, F);
+        rc |= proj(m, L, 6, L->down, gate, tmp, H, F);
         for (int i = 0; i < H; ++i) x[i] = tmp[i] + x[i];
         if (trace) memcpy(trace + (size_t)l * H, x, sizeof(float) * (size_t)H);
     }
