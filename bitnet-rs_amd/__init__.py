@@ -114,6 +114,9 @@ class HipLib:
         L.bitnet_hip_weights_info.argtypes = [C.c_uint64, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]
         L.bitnet_hip_gemv_dev.argtypes = [C.c_uint64, _vp, _vp, _vp]
         L.bitnet_hip_matmul_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp]
+        L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
+        L.bitnet_hip_matmul_workspace_bytes.restype = _sz
+        L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
         L.bitnet_hip_weights_concat.argtypes = [C.POINTER(C.c_uint64), _sz, C.c_int, C.POINTER(C.c_uint64)]
         L.bitnet_hip_gemv_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, _vp]
         L.bitnet_hip_rmsnorm.argtypes = [_f32p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, C.c_float]
@@ -246,6 +249,15 @@ class HipLib:
         h = C.c_uint64(0)
         self._check(self.c.bitnet_hip_weights_upload_inline_f16(b.ctypes.data_as(_u8p), b.size, n, k, cm.ctypes.data_as(_i8p), scale_mode, C.byref(h)))
         return h.value
+
+    def matmul_workspace_bytes(self, m: int, k: int, digits: int = 4) -> int:
+        return int(self.c.bitnet_hip_matmul_workspace_bytes(m, k, digits))
+
+    def matmul_fused_dev(self, h: int, x, y, m: int, workspace, workspace_bytes: int, ln_gamma=None, ln_eps: float = 0.0, residual=None,
+                         flags: int = 0, digits: int = 4, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_matmul_fused_dev(h, _ptr(x), _ptr(y), m, _ptr(ln_gamma) if ln_gamma is not None else None, ln_eps,
+                                                       _ptr(residual) if residual is not None else None, flags, digits, _ptr(workspace),
+                                                       workspace_bytes, _vp(stream)))
 
     def weights_free(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_free(h))

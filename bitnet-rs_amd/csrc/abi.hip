@@ -366,7 +366,51 @@ int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_d
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_dev");
     if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    const bool mfma_ok = g_kernel == BITNET_HIP_KERNEL_AUTO || g_kernel == BITNET_HIP_KERNEL_MFMA || g_kernel == BITNET_HIP_KERNEL_MFMA_TILED;
+    if (m >= 16 && mfma_ok && gemm_supported(*w)) {
+        // many rows: one tiled matmul instead of m GEMV launches; the digit-plane workspace lives
+        // for this call only (callers that care pass their own to bitnet_hip_matmul_fused_dev)
+        const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
+        void *ws = nullptr;
+        if (hipMalloc(&ws, wsb) != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed for the matmul workspace (%zu bytes)", wsb);
+        hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, GemvFusion(), 4, ws, wsb, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        hipFree(ws);
+        if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+        return BITNET_HIP_OK;
+    }
     return run_gemv(*w, x_dev, y_dev, m, GemvFusion(), (hipStream_t)stream);
+    BH_GUARD_END
+}
+
+size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits) {
+    return gemm_workspace_bytes(m, k, digits >= 2 && digits <= 4 ? digits : 4);
+}
+
+int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m,
+                                const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags, int digits,
+                                void *workspace_dev, size_t workspace_bytes, void *stream) {
+    BH_GUARD_BEGIN
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_fused_dev");
+    if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    if (digits < 2 || digits > 4) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "digits must be 2, 3 or 4, got %d", digits);
+    GemvFusion fu;
+    fu.ln_gamma = ln_gamma_dev;
+    fu.ln_eps = ln_eps;
+    fu.residual = residual_dev;
+    fu.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    if (fu.silu_mul && (!w->paired || residual_dev))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
+                         "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    if (!gemm_supported(*w)) return run_gemv(*w, x_dev, y_dev, m, fu, (hipStream_t)stream);  // 32-element block scales: row by row
+    const size_t need = gemm_workspace_bytes(m, w->cols, digits);
+    if (!workspace_dev || workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_dev ? workspace_bytes : (size_t)0);
+    hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
     BH_GUARD_END
 }
 

@@ -86,6 +86,11 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
                             hipStream_t stream);
 bool mfma_supported(const Weights &w);
 hipError_t build_tiles(Weights &w, hipStream_t stream);
+// many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
+bool gemm_supported(const Weights &w);
+size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);
+hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
+                            void *workspace, size_t workspace_bytes, hipStream_t stream);
 extern unsigned long long *g_mfma_stamps;  // diagnostic build only
 hipError_t launch_matmul_i2s_u8(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n,
                                 size_t k, hipStream_t stream);

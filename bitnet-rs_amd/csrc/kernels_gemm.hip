@@ -1,0 +1,405 @@
+// kernels_gemm.hip -- I2_S / QK256 matmul for MANY activation rows (prefill) on gfx950.
+//
+// Same arithmetic as the batch-1 GEMV (kernels_mfma.hip): every activation row is turned
+// into fixed point with one power-of-two scale per row, q = rint(x * 2^(S-E)), S = 8*NDIG-3,
+// split into NDIG balanced base-256 digits; each digit plane is an int8 matrix, the 2-bit
+// codes expand to int8 through the 4-entry code map (v_perm_b32), and
+// v_mfma_i32_16x16x64_i8 produces exact int32 sums per digit.  The epilogue recombines
+//     y[t, r] = 2^(E_t - S) * sum_d 256^d * D_d[r, t]        (only this line rounds)
+// NDIG = 4 is the 30-bit form the GEMV uses; NDIG = 3 (22 bits, about f32's own mantissa)
+// and NDIG = 2 (14 bits, finer than f16's 11) trade digits for matrix-core time.
+//
+//   k_quant_rows   one workgroup per activation row: [LayerNorm ->] max -> digits.
+//                  planes[row/16][digit][row%16][Kp] int8, Kp = nblk*256 (zero padded):
+//                  16 consecutive plane rows = one MFMA B tile (16 tokens of one digit),
+//                  so all digits of a token land in the SAME lane of different
+//                  accumulators and recombine in registers.
+//   k_gemm_mfma    workgroup tile 256 weight rows x (32*TTW) tokens, 8 waves as 4 (rows) x 2
+//                  (tokens); wave tile 64 rows x TTW*NDIG B tiles; K advances one 256-column
+//                  QK256 block per step: the activation tile goes global -> registers -> LDS
+//                  (next step's loads are in flight during this step's MFMAs), the weight
+//                  tiles are the GEMV's 1-KiB lane-ordered tiles, straight into registers.
+// Weights are read once per 32*TTW tokens (2 bits each: cheap); the int8 activation tile is
+// the larger stream and is shared by the 4 row-waves through LDS.
+#include <unordered_set>
+
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kColStride = 272;  // LDS bytes per activation column: 256 + 16 (conflict-free b128 reads)
+
+struct GemmArgs {
+    const uint8_t *tiles;  // [n_tiles][nblk][64][16]
+    int rows, cols, nblk;
+    uint32_t lut;
+    const int8_t *planes;    // [m_pad/16][NDIG][16][nblk*256]
+    const float *inv_scale;  // [m_pad] 2^(E-S) per activation row (0 for padding rows)
+    float *y;                // [m, rows] ([m, rows/2] with silu_mul)
+    int m;
+    const float *residual;  // optional [m, rows]
+    const float *wscale;    // optional f32 per (row, 256-block)
+    int silu_mul;
+};
+
+struct QuantArgs {
+    const float *x;  // [m, cols]
+    int m, m_pad, cols, kp;
+    const float *ln_gamma;
+    float ln_eps;
+    int8_t *planes;
+    float *inv_scale;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float qdpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float qwave_max(float v) {
+    v = fmaxf(v, qdpp_f<0xB1>(v));
+    v = fmaxf(v, qdpp_f<0x4E>(v));
+    v = fmaxf(v, qdpp_f<0x141>(v));
+    v = fmaxf(v, qdpp_f<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ double qwave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- activation rows -> digit planes --------------------------------------------------------
+// 256 threads per row, NV float4 per thread (cols <= 1024 * NV).
+template <int NDIG, int NV>
+__global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
+    constexpr int S = 8 * NDIG - 3;
+    __shared__ double stat[8];
+    __shared__ float smax[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nvec = p.cols >> 2, kvec = p.kp >> 2;
+    const bool live = row < p.m;
+    const int rr = live ? row : p.m - 1;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, ci = idx < nvec ? idx : nvec - 1;
+        v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        if (idx >= nvec || !live) v[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.ln_gamma) {
+        // LayerNorm without bias, with mean subtraction (T:67-100), one pass in f64 like the GEMV prologue
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double a = v[i].x, b = v[i].y, c = v[i].z, d = v[i].w;
+            s1 += (a + b) + (c + d);
+            s2 += (a * a + b * b) + (c * c + d * d);
+        }
+        s1 = qwave_sum_d(s1);
+        s2 = qwave_sum_d(s2);
+        if (lane == 0) {
+            stat[2 * wave] = s1;
+            stat[2 * wave + 1] = s2;
+        }
+        __syncthreads();
+        s1 = (stat[0] + stat[2]) + (stat[4] + stat[6]);
+        s2 = (stat[1] + stat[3]) + (stat[5] + stat[7]);
+        const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
+        const float mean = (float)mean_d, denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nvec && live) {
+                const float4 g = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * idx);
+                v[i].x = (v[i].x - mean) / denom * g.x;
+                v[i].y = (v[i].y - mean) / denom * g.y;
+                v[i].z = (v[i].z - mean) / denom * g.z;
+                v[i].w = (v[i].w - mean) / denom * g.w;
+            }
+        }
+    }
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    am = qwave_max(am);
+    if (lane == 0) smax[wave] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
+    be = be < 32 ? 32 : be;
+    const float sc = __uint_as_float((uint32_t)(254 + S - be) << 23);     // 2^(S - E)
+    const float inv_s = __uint_as_float((uint32_t)(be - S) << 23);        // 2^(E - S)
+    if (tid == 0) p.inv_scale[row] = live ? inv_s : 0.0f;
+    int8_t *base = p.planes + ((size_t)(row >> 4) * NDIG * 16 + (row & 15)) * p.kp;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx >= kvec) continue;
+        uint32_t dg[NDIG];
+#pragma unroll
+        for (int d = 0; d < NDIG; ++d) dg[d] = 0;
+        const float e4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int q = __float2int_rn(e4[b] * sc);
+#pragma unroll
+            for (int d = 0; d < NDIG - 1; ++d) {
+                const int e = (int)(int8_t)q;
+                q = (q - e) >> 8;
+                dg[d] |= (uint32_t)(e & 0xff) << (8 * b);
+            }
+            dg[NDIG - 1] |= (uint32_t)(q & 0xff) << (8 * b);
+        }
+#pragma unroll
+        for (int d = 0; d < NDIG; ++d) *reinterpret_cast<uint32_t *>(base + (size_t)d * 16 * p.kp + 4 * idx) = dg[d];
+    }
+}
+
+__device__ __forceinline__ v4i gdecode16(uint32_t w, uint32_t lut) {
+    v4i a;
+    a[0] = (int)__builtin_amdgcn_perm(0u, lut, w & 0x03030303u);
+    a[1] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 2) & 0x03030303u);
+    a[2] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 4) & 0x03030303u);
+    a[3] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 6) & 0x03030303u);
+    return a;
+}
+
+template <int NDIG>
+__device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
+    // ((d0 + 256 d1) + (65536 d2 + 2^24 d3)): the GEMV's order
+    if (NDIG == 2) return (float)acc[0][j] + 256.0f * (float)acc[1][j];
+    if (NDIG == 3) return ((float)acc[0][j] + 256.0f * (float)acc[1][j]) + 65536.0f * (float)acc[2][j];
+    return ((float)acc[0][j] + 256.0f * (float)acc[1][j]) + (65536.0f * (float)acc[2][j] + 16777216.0f * (float)acc[3][j]);
+}
+
+template <int NDIG, int TTW, bool WS>
+__global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
+    constexpr int CT = NDIG * TTW;          // B tiles per wave
+    constexpr int WG_COLS = 2 * CT * 16;    // plane rows per workgroup
+    constexpr int NB = WG_COLS * 16 / 512;  // uint4 per thread per K step
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4, rw = wave & 3, cw = wave >> 2;
+    const int n_tiles = (p.rows + 15) >> 4;
+    const int kp = p.nblk * 256;
+
+    // this wave's four weight row tiles (clamped: surplus tiles recompute the last one, never stored)
+    const uint8_t *wptr[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        int t = blockIdx.x * 16 + rw * 4 + rt;
+        t = t < n_tiles ? t : n_tiles - 1;
+        wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
+    }
+    // this thread's share of the activation tile
+    const int8_t *bsrc[NB];
+    int bdst[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + 512 * i, col = idx >> 4, seg = idx & 15;
+        bsrc[i] = p.planes + (size_t)(blockIdx.y * WG_COLS + col) * kp + seg * 16;
+        bdst[i] = col * kColStride + seg * 16;
+    }
+    uint4 wn[4], bn[NB];
+    if (!WS) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i]);
+    }
+
+    v4i acc[4][CT];
+    float facc[WS ? 4 : 1][WS ? TTW : 1][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4i){0, 0, 0, 0};
+    if (WS) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < TTW; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) facc[rt][tt][j] = 0.0f;
+    }
+    const uint8_t *bread = lds + (cw * CT * 16 + c) * kColStride + 64 * g;
+
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        uint4 wt[4];
+        if (WS) {  // scaled variant: registers go to the f32 accumulators, no prefetch
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)blk * 1024);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)blk * 256);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) wt[rt] = wn[rt];
+        __syncthreads();  // the previous step's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
+        __syncthreads();
+        if (!WS) {
+            // next step's loads fly during this step's MFMAs (clamped on the last step)
+            const int nx = blk + 1 < p.nblk ? blk + 1 : blk;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)nx * 1024);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)nx * 256);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            v4i a[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const uint32_t wd = m == 0 ? wt[rt].x : m == 1 ? wt[rt].y : m == 2 ? wt[rt].z : wt[rt].w;
+                a[rt] = gdecode16(wd, p.lut);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const v4i b = *reinterpret_cast<const v4i *>(bread + ct * 16 * kColStride + 16 * m);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
+            }
+        }
+        if (WS) {
+            // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                int t = blockIdx.x * 16 + rw * 4 + rt;
+                t = t < n_tiles ? t : n_tiles - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int row = 16 * t + 4 * g + j;
+                    row = row < p.rows ? row : p.rows - 1;
+                    const float s = p.wscale[(size_t)row * p.nblk + blk];
+#pragma unroll
+                    for (int tt = 0; tt < TTW; ++tt) facc[rt][tt][j] += combine_digits<NDIG>(&acc[rt][tt * NDIG], j) * s;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4i){0, 0, 0, 0};
+            }
+        }
+    }
+
+    // ---- epilogue: digits -> f32, x 2^(E_t - S), [residual | silu*mul], store ------------------
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        const int token = (blockIdx.y * 2 * TTW + cw * TTW + tt) * 16 + c;
+        if (token >= p.m) continue;
+        const float is = p.inv_scale[token];
+        float val[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[rt][j] = (WS ? facc[rt][tt][j] : combine_digits<NDIG>(&acc[rt][tt * NDIG], j)) * is;
+        if (!p.silu_mul) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int row0 = 16 * (blockIdx.x * 16 + rw * 4 + rt) + 4 * g;
+                const size_t off = (size_t)token * p.rows + row0;
+                if (row0 + 3 < p.rows && (p.rows & 3) == 0) {
+                    float4 o = {val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
+                    if (p.residual) {
+                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
+                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+                    }
+                    *reinterpret_cast<float4 *>(p.y + off) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + j < p.rows) p.y[off + j] = val[rt][j] + (p.residual ? p.residual[off + j] : 0.0f);
+                }
+            }
+        } else {
+            // row tiles alternate (gate, up): FeedForward::forward T:756-781, silu(v) = v / (1 + exp(-v))
+            const int half_rows = p.rows >> 1;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int row0 = 16 * (blockIdx.x * 8 + rw * 2 + pr) + 4 * g;
+                const size_t off = (size_t)token * half_rows + row0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
+                    if (row0 + j < half_rows) p.y[off + j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static int gemm_ttw(int ndig, bool ws) { return (ndig == 2 && !ws) ? 4 : 2; }
+
+bool gemm_supported(const Weights &w) {
+    if (!w.tiles || w.cols % 4 != 0 || w.cols > 8192) return false;
+    if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;
+    if (w.scales && w.block_size != 256) return false;  // 32-element block scales: GEMV path only
+    return true;
+}
+
+size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig) {
+    const size_t wg_tokens = 128, m_pad = div_ceil(m, wg_tokens) * wg_tokens;
+    const size_t kp = div_ceil(cols, 256) * 256;
+    return m_pad * ndig * kp + div_ceil(m_pad * sizeof(float), 256) * 256 + 256;
+}
+
+template <int NDIG, int TTW>
+static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
+    const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
+    void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<NDIG, 3> : k_quant_rows<NDIG, 8>;
+    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
+    constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
+    void (*gk)(GemmArgs) = a.wscale ? k_gemm_mfma<NDIG, TTWS, true> : k_gemm_mfma<NDIG, TTW, false>;
+    const int ttw = a.wscale ? TTWS : TTW;
+    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride;
+    static std::unordered_set<const void *> raised;  // once per kernel
+    if (!raised.count((const void *)gk)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised.insert((const void *)gk);
+    }
+    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (32 * ttw));
+    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
+                            void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
+    if (workspace_bytes < gemm_workspace_bytes(m, w.cols, ndig) || !workspace) return hipErrorInvalidValue;
+    const bool ws_mode = w.scales && w.block_size == 256;
+    const size_t wg_tokens = (size_t)32 * gemm_ttw(ndig, ws_mode), m_pad = div_ceil(m, wg_tokens) * wg_tokens;
+    QuantArgs q;
+    q.x = x;
+    q.m = (int)m;
+    q.m_pad = (int)m_pad;
+    q.cols = (int)w.cols;
+    q.kp = (int)(div_ceil(w.cols, 256) * 256);
+    q.ln_gamma = fu.ln_gamma;
+    q.ln_eps = fu.ln_eps;
+    uint8_t *ws = static_cast<uint8_t *>(workspace);
+    ws = reinterpret_cast<uint8_t *>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    q.inv_scale = reinterpret_cast<float *>(ws);
+    q.planes = reinterpret_cast<int8_t *>(ws + div_ceil(m_pad * 4, 256) * 256);
+    GemmArgs a;
+    a.tiles = w.tiles;
+    a.rows = (int)w.rows;
+    a.cols = (int)w.cols;
+    a.nblk = (int)div_ceil(w.cols, 256);
+    a.lut = w.lut;
+    a.planes = q.planes;
+    a.inv_scale = q.inv_scale;
+    a.y = y;
+    a.m = (int)m;
+    a.residual = fu.residual;
+    a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
+    a.silu_mul = fu.silu_mul ? 1 : 0;
+    if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
+    if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
+    return launch_gemm_t<4, 2>(w, q, a, stream);
+}
+
+}  // namespace bitnet_hip

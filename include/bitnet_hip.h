@@ -189,6 +189,15 @@ int bitnet_hip_gemv_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev
  * batched; row-major, leading dimensions cols / rows) */
 int bitnet_hip_matmul_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                           void *stream);
+/* Many activation rows at once (prefill; forward_qk256's per-row loop T:683-691 as ONE tiled
+ * matmul on the matrix cores).  Same fusions as gemv_fused_dev, per row.  `digits` = base-256
+ * fixed-point digits per activation (4: the GEMV's 30 bits; 3: 22 bits; 2: 14 bits).
+ * The int8 digit planes live in a caller-owned device workspace. */
+size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
+int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
+                                const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
+                                int flags, int digits, void *workspace_dev, size_t workspace_bytes,
+                                void *stream);
 
 /* Several uploaded matrices with the same cols / code map / block size as ONE
  * launch: rows concatenated (q|k|v share their input: T:288-290).  interleave16 != 0

@@ -1,0 +1,132 @@
+"""GPU parity of the many-row (prefill) matmul, kernels_gemm.hip, through the C ABI
+(bitnet_hip_matmul_fused_dev / bitnet_hip_matmul_dev) against the CPU oracle's row-by-row
+restatement of gemv_qk256 (Q/i2s_qk256.rs:196-321) and i2s_matmul_f32
+(K/cpu/quantized_matmul.rs:57-96).  Tolerance: the reference's own approx_eq_with_len
+(crates/bitnet-models/tests/helpers/qk256_tolerance.rs) for 3 and 4 digits; 2 digits
+(14-bit activations) is gated on cosine >= 0.99999 (benches/qk256_gemv.rs:234)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def approx_tol(cols):
+    return min(2e-4 * np.sqrt(cols / 256.0), 1e-3)
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+
+    return torch
+
+
+def run_gemm(hip, torch_, h, x, out_cols, digits, **kw):
+    m, k = x.shape
+    wsb = hip.matmul_workspace_bytes(m, k, digits)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    xd = torch_.from_numpy(x).cuda()
+    yd = torch_.full((m, out_cols), float("nan"), device="cuda")
+    hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, digits=digits, **kw)
+    torch_.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("rows,cols,m", [(256, 256, 16), (640, 2560, 64), (2560, 2560, 100), (1000, 300, 37), (320, 6912, 130), (48, 512, 1)])
+def test_qk256_gemm_matches_oracle_rows(hip, oracle, torch_, rows, cols, m):
+    rng = np.random.default_rng(rows + cols + m)
+    stride = -(-cols // 256) * 64
+    qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+    x = rng.uniform(-10, 10, (m, cols)).astype(np.float32)  # crates/bitnet-models/tests/qk256_avx2_correctness.rs:101-104
+    x[m // 2] *= 1e-3  # rows of very different magnitude: the scale is per row
+    want = np.stack([oracle.gemv_qk256(qs, x[i], rows, cols, stride) for i in range(m)])
+    h = hip.weights_upload_qk256(qs, rows, cols, stride)
+    for digits in (4, 3, 2):
+        got = run_gemm(hip, torch_, h, x, rows, digits)
+        assert not np.isnan(got).any()
+        if digits >= 3:
+            # approx_eq_with_len: abs tol 2e-4*sqrt(cols/256) (<= 1e-3) or 2 % relative; the scalar
+            # reference itself rounds ~1e-7*sum|x| per element, so the test scales the abs tol by the row's magnitude
+            scale = np.maximum(1.0, np.abs(x).sum(axis=1, keepdims=True) * 2e-7 / approx_tol(cols))
+            assert np.all((np.abs(got - want) <= approx_tol(cols) * scale) | (np.abs(got - want) <= 2e-2 * np.abs(want))), (digits, np.abs(got - want).max())
+        for i in range(m):
+            assert cosine(got[i], want[i]) >= 0.99999, (digits, i)
+    # 4 digits agrees with the GEMV path (same arithmetic, per-wave instead of per-row scale) to f32 rounding
+    xd = torch_.from_numpy(x).cuda()
+    yv = torch_.empty(m, rows, device="cuda")
+    for i in range(m):
+        hip.gemv_dev(h, xd[i], yv[i])
+    torch_.cuda.synchronize()
+    got4 = run_gemm(hip, torch_, h, x, rows, 4)
+    denom = np.abs(x).sum(axis=1, keepdims=True) * 2.0
+    assert np.max(np.abs(got4 - yv.cpu().numpy()) / denom) <= 3e-7
+    # bitnet_hip_matmul_dev takes the same path for m >= 16
+    yd = torch_.empty(m, rows, device="cuda")
+    hip.matmul_dev(h, xd, yd, m)
+    torch_.cuda.synchronize()
+    if m >= 16:
+        assert np.array_equal(yd.cpu().numpy(), got4)
+    hip.weights_free(h)
+
+
+def test_gemm_fusions_ln_residual_silu(hip, oracle, torch_):
+    rng = np.random.default_rng(77)
+    K, N, m = 2560, 512, 48
+    stride = K // 256 * 64
+    qa = rng.integers(0, 256, N * stride, dtype=np.uint8)
+    qb = rng.integers(0, 256, N * stride, dtype=np.uint8)
+    x = rng.normal(0.1, 1.0, (m, K)).astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, K) / 80).astype(np.float32)
+    res = rng.normal(0, 1, (m, N)).astype(np.float32)
+    ha, hb = hip.weights_upload_qk256(qa, N, K, stride), hip.weights_upload_qk256(qb, N, K, stride)
+    gd, rd = torch_.from_numpy(g).cuda(), torch_.from_numpy(res).cuda()
+    xn = np.stack([oracle.layernorm(x[i], g, 1e-5) for i in range(m)])
+    ya = np.stack([oracle.gemv_qk256(qa, xn[i], N, K, stride) for i in range(m)])
+    yb = np.stack([oracle.gemv_qk256(qb, xn[i], N, K, stride) for i in range(m)])
+    tol = lambda want: 3e-5 * np.max(np.abs(want)) + 1e-6
+    for digits in (4, 3):
+        got = run_gemm(hip, torch_, ha, x, N, digits, ln_gamma=gd, ln_eps=1e-5, residual=rd)
+        assert np.max(np.abs(got - (ya + res))) <= tol(ya), digits
+    hc = hip.weights_concat([ha, hb])
+    got = run_gemm(hip, torch_, hc, x, 2 * N, 4, ln_gamma=gd, ln_eps=1e-5)
+    assert np.max(np.abs(got - np.concatenate([ya, yb], axis=1))) <= tol(ya)
+    hg = hip.weights_concat([ha, hb], interleave16=True)
+    got = run_gemm(hip, torch_, hg, x, N, 4, ln_gamma=gd, ln_eps=1e-5, flags=1)
+    want = (ya / (1 + np.exp(-ya.astype(np.float64)))).astype(np.float32) * yb
+    assert np.max(np.abs(got - want)) <= 3e-5 * np.max(np.abs(want)) + 1e-6
+    # in place: y aliases the residual (x = x + W h)
+    yd = rd.clone()
+    wsb = hip.matmul_workspace_bytes(m, K, 4)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    hip.matmul_fused_dev(ha, torch_.from_numpy(x).cuda(), yd, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, residual=yd)
+    torch_.cuda.synchronize()
+    assert np.max(np.abs(yd.cpu().numpy() - (ya + res))) <= tol(ya)
+    with pytest.raises(Exception, match="workspace too small"):
+        hip.matmul_fused_dev(ha, rd, yd, m, ws, 16)
+    with pytest.raises(Exception, match="digits must be"):
+        hip.matmul_fused_dev(ha, rd, yd, m, ws, wsb, digits=5)
+    for h in (ha, hb, hc, hg):
+        hip.weights_free(h)
+
+
+@pytest.mark.parametrize("block", [256, 32])
+def test_ternary_scaled_gemm(hip, oracle, torch_, block):
+    """i2s_matmul_f32 semantics with m rows: 256-element scales run in the tiled kernel, 32-element
+    block scales fall back to the per-row GEMV inside the same entry point."""
+    rng = np.random.default_rng(block)
+    n, k, m = 384, 1024, 40
+    codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(n, k), p=[0.5, 0.25, 0.25])
+    packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
+    scales = (1.0 / ((np.arange(n * (k // block)) % 100) + 1)).astype(np.float32)
+    x = rng.uniform(-4, 4, (m, k)).astype(np.float32)
+    want = oracle.i2s_matmul(x.reshape(-1), packed.reshape(-1), scales, m, n, k, block).reshape(m, n)
+    h = hip.weights_upload_i2s(packed.reshape(-1), scales, n, k, block)
+    for digits in (4, 3):
+        got = run_gemm(hip, torch_, h, x, n, digits)
+        assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)) + 1e-6, (block, digits)
+    hip.weights_free(h)
