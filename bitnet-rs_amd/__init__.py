@@ -124,6 +124,9 @@ class HipLib:
         L.bitnet_hip_embed_f16_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]
         L.bitnet_hip_advance_pos_dev.argtypes = [_vp, _vp]
         L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_attention_prefill_workspace_bytes.argtypes = [_sz, _sz, _sz]
+        L.bitnet_hip_attention_prefill_workspace_bytes.restype = _sz
+        L.bitnet_hip_attention_prefill_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]
         L.bitnet_hip_attention_scratch_bytes.argtypes = [_sz, _sz]
         L.bitnet_hip_attention_scratch_bytes.restype = _sz
         L.bitnet_hip_logits_f16_dev.argtypes = [_vp, _vp, _vp, C.c_float, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
@@ -258,6 +261,14 @@ class HipLib:
         self._check(self.c.bitnet_hip_matmul_fused_dev(h, _ptr(x), _ptr(y), m, _ptr(ln_gamma) if ln_gamma is not None else None, ln_eps,
                                                        _ptr(residual) if residual is not None else None, flags, digits, _ptr(workspace),
                                                        workspace_bytes, _vp(stream)))
+
+    def attention_prefill_workspace_bytes(self, n_heads: int, n_kv: int, seq_len: int) -> int:
+        return int(self.c.bitnet_hip_attention_prefill_workspace_bytes(n_heads, n_kv, seq_len))
+
+    def attention_prefill_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, seq_len, workspace,
+                              workspace_bytes, out, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_prefill_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
+                                                            head_dim, max_pos, seq_len, _ptr(workspace), workspace_bytes, _ptr(out), _vp(stream)))
 
     def weights_free(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_free(h))
@@ -508,6 +519,12 @@ class HostDecoder:
     def run(self, n: int, with_logits: bool = True, use_graph: bool = True) -> float:
         ms = C.c_float(0)
         self._check(self.c.bitnet_host_run(self.h, n, int(with_logits), int(use_graph), C.byref(ms)))
+        return ms.value
+
+    def prefill(self, n: int, with_logits: bool = True, digits: int = 4) -> float:
+        self.c.bitnet_host_prefill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        ms = C.c_float(0)
+        self._check(self.c.bitnet_host_prefill(self.h, n, int(with_logits), digits, C.byref(ms)))
         return ms.value
 
     def position(self) -> int:

@@ -561,6 +561,30 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
     BH_GUARD_END
 }
 
+size_t bitnet_hip_attention_prefill_workspace_bytes(size_t n_heads, size_t n_kv_heads, size_t seq_len) {
+    return attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len);
+}
+
+int bitnet_hip_attention_prefill_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                                     float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                     size_t seq_len, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !workspace || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_prefill_dev");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim != 128) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_prefill: head_dim %zu unsupported (128)", head_dim);
+    if (seq_len == 0 || seq_len > max_pos)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "KV cache overflow: seq_len %zu, max_pos %zu", seq_len, max_pos);  // T:1190-1194
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len);
+    if (workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
+    BH_HIP_TRY(launch_attn_prefill(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                   (int)max_pos, (int)seq_len, workspace, workspace_bytes, out, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos) {
     return attn_scratch_floats((int)n_kv_heads, (int)max_pos) * sizeof(float);
 }

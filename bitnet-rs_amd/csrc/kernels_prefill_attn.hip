@@ -1,0 +1,238 @@
+// kernels_prefill_attn.hip -- causal self-attention over a whole prompt (prefill) on gfx950.
+//
+// The reference runs the same per-head softmax(Q K^T / sqrt(d) + causal mask) V for a
+// [T]-token forward (T:410-533) with RoPE applied to q and k (T:134-163) and k, v appended
+// to the cache (T:1171-1202).  Here, for a FRESH sequence (positions 0..T-1):
+//
+//   k_prefill_prep  grid (T/64, heads + 2*kv_heads): one 64-token x 128-dim slab of q, k or v
+//                   through LDS: RoPE (q, k); q -> f16 [head][T][128]; k -> f16 [kv][T][128]
+//                   and the f32 decode cache (transposed, [kv][128][max_pos]); v -> f16
+//                   transposed [kv][128][T] and the f32 decode cache [kv][max_pos][128].
+//                   Every global access is contiguous along the fastest index.
+//   k_prefill_attn  grid (T/64, heads), 4 waves x 16 queries: flash attention on
+//                   v_mfma_f32_16x16x32_f16, f32 accumulation and f32 online softmax.
+//                   It works on S^T = K Q^T and O^T = V^T P^T so that the probabilities never
+//                   leave registers: an S^T accumulator (lane: query c, keys 4g..4g+3) is
+//                   already in B-operand form for the second product once the V^T operand
+//                   uses the same key -> k-slot map.
+// q, k, v and the probabilities are rounded to f16 for the matrix cores (relative 2^-11);
+// the KV cache the decode steps read afterwards is the exact f32 values.
+#include "common.hpp"
+
+namespace bitnet_hip {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kPD = 128;       // head dim
+constexpr int kQB = 64;        // queries / keys per block
+constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
+constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
+
+struct PrefillArgs {
+    const float *qkv;  // [T, (heads + 2 kv) * 128]
+    const float *rope_sin, *rope_cos;
+    float *kcache, *vcache;
+    int n_heads, n_kv, max_pos, T, Tpad;
+    _Float16 *qh, *kh, *vt;  // workspace
+    float *out;              // [T, heads * 128]
+};
+
+__global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
+    __shared__ float tile[kQB][kPD + 1];
+    const int slot = blockIdx.y, t0 = blockIdx.x * kQB, tid = threadIdx.x;
+    const int ld = (p.n_heads + 2 * p.n_kv) * kPD;
+    for (int i = 0; i < 32; ++i) {
+        const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+        tile[tok][d] = t0 + tok < p.T ? p.qkv[(size_t)(t0 + tok) * ld + (size_t)slot * kPD + d] : 0.0f;
+    }
+    __syncthreads();
+    const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
+    if (is_q || is_k) {
+        // split-half RoPE (crates/bitnet-rope/src/lib.rs:59-93, T:134-163): pairs (j, j + 64)
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, tok = idx >> 6, j = idx & 63;
+            const int pos = t0 + tok < p.T ? t0 + tok : 0;
+            const float s = p.rope_sin[(size_t)pos * 64 + j], c = p.rope_cos[(size_t)pos * 64 + j];
+            const float x0 = tile[tok][j], x1 = tile[tok][64 + j];
+            tile[tok][j] = x0 * c - x1 * s;
+            tile[tok][64 + j] = x0 * s + x1 * c;
+        }
+        __syncthreads();
+    }
+    if (is_q) {
+        _Float16 *dst = p.qh + ((size_t)slot * p.Tpad + t0) * kPD;
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i;
+            dst[idx] = (_Float16)tile[idx >> 7][idx & 127];
+        }
+    } else if (is_k) {
+        const int kvh = slot - p.n_heads;
+        _Float16 *dst = p.kh + ((size_t)kvh * p.Tpad + t0) * kPD;
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i;
+            dst[idx] = (_Float16)tile[idx >> 7][idx & 127];
+        }
+        float *kt = p.kcache + (size_t)kvh * kPD * p.max_pos;  // [128][max_pos]
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
+            if (t0 + tok < p.T) kt[(size_t)d * p.max_pos + t0 + tok] = tile[tok][d];
+        }
+    } else {
+        const int kvh = slot - p.n_heads - p.n_kv;
+        float *vc = p.vcache + (size_t)kvh * p.max_pos * kPD;  // [max_pos][128]
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+            if (t0 + tok < p.T) vc[(size_t)(t0 + tok) * kPD + d] = tile[tok][d];
+        }
+        _Float16 *vt = p.vt + (size_t)kvh * kPD * p.Tpad;  // [128][Tpad]
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
+            vt[(size_t)d * p.Tpad + t0 + tok] = (_Float16)tile[tok][d];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
+    __shared__ __attribute__((aligned(16))) uint8_t ks[kQB * kKPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t vs[kPD * kVPitch];
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
+    const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int qpos = qb * kQB + wave * 16 + c;  // this lane's query (B-operand column)
+    // Q^T operand: 8 consecutive dims per k-slot group, kept in registers for the whole block
+    v8h qreg[4];
+    {
+        const _Float16 *qp = p.qh + ((size_t)h * p.Tpad + qpos) * kPD + 8 * g;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) qreg[ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
+    }
+    v4f o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float scale_log2 = 1.4426950408889634f / sqrtf((float)kPD);  // softmax in base 2
+    const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
+    const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
+
+    for (int kt = 0; kt <= qb; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            {   // K tile: 64 keys x 128 dims, contiguous 16 KB
+                const int pos = idx >> 4, seg = idx & 15;
+                *reinterpret_cast<uint4 *>(ks + pos * kKPitch + seg * 16) =
+                    *reinterpret_cast<const uint4 *>(kbase + ((size_t)(kt * kQB + pos)) * kPD + seg * 8);
+            }
+            {   // V^T tile: 128 dims x 64 keys
+                const int d = idx >> 3, seg = idx & 7;
+                *reinterpret_cast<uint4 *>(vs + d * kVPitch + seg * 16) =
+                    *reinterpret_cast<const uint4 *>(vbase + (size_t)d * p.Tpad + kt * kQB + seg * 8);
+            }
+        }
+        __syncthreads();
+        // ---- S^T = K Q^T: 4 key tiles of 16, reduced over 4 dim chunks of 32 ----------------------
+        v4f s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v8h a = *reinterpret_cast<const v8h *>(ks + (16 * i + c) * kKPitch + (32 * ch + 8 * g) * 2);
+                s[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[ch], s[i], 0, 0, 0);
+            }
+        // ---- online softmax for query column c (keys of this lane: 16 i + 4 g + j) ---------------
+        float mt = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = kt * kQB + 16 * i + 4 * g + j;
+                const float v = pos <= qpos ? s[i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470)
+                s[i][j] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);  // finite: key 0 is visible to every query
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = __builtin_amdgcn_exp2f(s[i][j] - m_new);
+                s[i][j] = e;
+                lsum += e;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+        // ---- O^T += V^T P^T: k-slot (g, j) = key 32u + 4g + j (j < 4), 32u + 16 + 4g + (j - 4) ------
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v8h pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pb[j] = (_Float16)s[2 * u][j];
+                pb[4 + j] = (_Float16)s[2 * u + 1][j];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const uint8_t *vp = vs + (16 * dt + c) * kVPitch + (32 * u + 4 * g) * 2;
+                const v4h lo = *reinterpret_cast<const v4h *>(vp), hi = *reinterpret_cast<const v4h *>(vp + 32);
+                const v8h a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (qpos < p.T) {
+        const float inv = 1.0f / l_run;
+        float *op = p.out + (size_t)qpos * p.n_heads * kPD + (size_t)h * kPD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const float4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+            *reinterpret_cast<float4 *>(op + 16 * dt) = v;
+        }
+    }
+}
+
+size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int T) {
+    const size_t tpad = div_ceil((size_t)T, kQB) * kQB;
+    return ((size_t)n_heads + 2 * (size_t)n_kv) * tpad * kPD * sizeof(_Float16) + 256;
+}
+
+hipError_t launch_attn_prefill(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache, float *vcache,
+                               int n_heads, int n_kv, int D, int max_pos, int T, void *workspace, size_t workspace_bytes,
+                               float *out, hipStream_t stream) {
+    if (D != kPD || T <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
+    if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, T)) return hipErrorInvalidValue;
+    PrefillArgs p;
+    p.qkv = qkv;
+    p.rope_sin = rope_sin;
+    p.rope_cos = rope_cos;
+    p.kcache = kcache;
+    p.vcache = vcache;
+    p.n_heads = n_heads;
+    p.n_kv = n_kv;
+    p.max_pos = max_pos;
+    p.T = T;
+    p.Tpad = (int)(div_ceil((size_t)T, kQB) * kQB);
+    uint8_t *ws = reinterpret_cast<uint8_t *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    p.qh = reinterpret_cast<_Float16 *>(ws);
+    p.kh = p.qh + (size_t)n_heads * p.Tpad * kPD;
+    p.vt = p.kh + (size_t)n_kv * p.Tpad * kPD;
+    p.out = out;
+    const unsigned nb = (unsigned)(p.Tpad / kQB);
+    hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_prefill_attn, dim3(nb, (unsigned)n_heads), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace bitnet_hip

@@ -102,6 +102,8 @@ Decoder::~Decoder() {
                     (void *)qkv_, (void *)att_, (void *)h_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
+    for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
+        if (p) hipFree(p);
     if (stream_) hipStreamDestroy((hipStream_t)stream_);
 }
 
@@ -320,6 +322,80 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
     return 0;
 }
 
+int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    if (p != 0) {
+        err_ = "prefill needs a fresh sequence (position 0): reset() first";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (n <= 0 || n > host_forced_) {
+        err_ = "prefill: feed() the prompt tokens first";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (n > c_.max_pos - 1) {
+        err_ = "KV cache overflow";  // T:1190-1194
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    if (n > pf_cap_) {
+        for (void *q : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
+            if (q) hipFree(q);
+        pf_x_ = pf_qkv_ = pf_att_ = pf_h_ = nullptr;
+        pf_gemm_ws_ = pf_attn_ws_ = nullptr;
+        pf_cap_ = 0;
+        const size_t N = (size_t)n;
+        pf_gemm_ws_bytes_ = bitnet_hip_matmul_workspace_bytes(N, H > F ? H : F, 4);
+        pf_attn_ws_bytes_ = bitnet_hip_attention_prefill_workspace_bytes((size_t)c_.n_heads, (size_t)c_.n_kv_heads, N);
+        HCHK(dalloc(&pf_x_, N * H));
+        HCHK(dalloc(&pf_qkv_, N * (QD + 2 * KD)));
+        HCHK(dalloc(&pf_att_, N * QD));
+        HCHK(dalloc(&pf_h_, N * F));
+        HCHK(hipMalloc(&pf_gemm_ws_, pf_gemm_ws_bytes_));
+        HCHK(hipMalloc(&pf_attn_ws_, pf_attn_ws_bytes_));
+        pf_cap_ = n;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    hipEvent_t e0, e1;
+    HCHK(hipEventCreate(&e0));
+    HCHK(hipEventCreate(&e1));
+    HCHK(hipEventRecord(e0, s));
+    const size_t N = (size_t)n;
+    BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, N, H, (size_t)c_.vocab, pf_x_, s));  // *pos_ == 0
+    for (auto &L : layers_) {
+        BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_attention_prefill_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                              (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
+                                         pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+    }
+    // hand over to the single-token state: residual stream of the last position, position counter
+    HCHK(hipMemcpyAsync(x_, pf_x_ + (N - 1) * H, H * 4, hipMemcpyDeviceToDevice, s));
+    const int32_t last = n - 1;
+    HCHK(hipMemcpyAsync(pos_, &last, 4, hipMemcpyHostToDevice, s));
+    HCHK(hipStreamSynchronize(s));  // `last` is a stack variable
+    if (with_logits) {
+        BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_,
+                                       pos_, history_, n_forced_, s));
+    } else {
+        BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+    }
+    HCHK(hipEventRecord(e1, s));
+    HCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
 int Decoder::history(int32_t *out, int n) {
     HCHK(hipMemcpy(out, history_, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -455,6 +531,9 @@ int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
 int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);
+}
+int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms) {
+    return static_cast<Decoder *>(d)->prefill(n, with_logits != 0, digits, elapsed_ms);
 }
 int bitnet_host_position(void *d) { return static_cast<Decoder *>(d)->position(); }
 int bitnet_host_history(void *d, int32_t *out, int n) { return static_cast<Decoder *>(d)->history(out, n); }

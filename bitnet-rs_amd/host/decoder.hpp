@@ -79,6 +79,12 @@ class Decoder {
     // logits GEMV for prompt positions nobody samples from.  Uses the captured graph
     // when use_graph, else eager launches.  Synchronises the stream before returning.
     int run(int n, bool with_logits, bool use_graph, float *elapsed_ms);
+    // Whole-prompt forward on a fresh sequence (position() == 0): the first n fed tokens go
+    // through every layer as [n, *] matrices (TransformerModel::forward with seq_len n,
+    // T:1557-1597): tiled matmuls + causal attention, KV cache filled for positions 0..n-1.
+    // with_logits samples the token after the prompt exactly as run() does for the last
+    // prompt position.  digits: fixed-point digits per activation in the matmuls (2..4).
+    int prefill(int n, bool with_logits, int digits, float *elapsed_ms);
     int position();                                  // tokens consumed so far
     int history(int32_t *out, int n);                // first n tokens of the sequence
     int last_logits(float *out);                     // [vocab], of the last step run with logits
@@ -115,6 +121,11 @@ class Decoder {
     float *attn_scratch_ = nullptr;
     int32_t *pos_ = nullptr, *n_forced_ = nullptr, *history_ = nullptr, *token_ = nullptr;
     int host_forced_ = 0;
+    // prefill buffers (grown on demand)
+    int pf_cap_ = 0;
+    float *pf_x_ = nullptr, *pf_qkv_ = nullptr, *pf_att_ = nullptr, *pf_h_ = nullptr;
+    void *pf_gemm_ws_ = nullptr, *pf_attn_ws_ = nullptr;
+    size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;
     void *graph_exec_[2] = {nullptr, nullptr};  // [with_logits]
     void *graph_[2] = {nullptr, nullptr};
@@ -141,6 +152,7 @@ int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *fin
 int bitnet_host_reset(void *d);
 int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
+int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_position(void *d);
 int bitnet_host_history(void *d, int32_t *out, int n);
 int bitnet_host_last_logits(void *d, float *out);

@@ -248,6 +248,19 @@ int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_
                                     size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                     const int32_t *pos_dev, float *scratch_dev, float *out_dev,
                                     void *stream);
+/* The same attention for a whole prompt of seq_len tokens on a FRESH cache (positions
+ * 0..seq_len-1): RoPE, cache append, causal GQA softmax attention (T:398-543 with the causal
+ * mask T:452-470).  qkv_dev: [seq_len, n_heads*D + 2*n_kv*D]; out_dev: [seq_len, n_heads*D].
+ * q, k, v and the probabilities go through the matrix cores in f16 (f32 accumulate); the
+ * cache receives the exact f32 k, v.  Semantics of the reference's stub
+ * fused_attention_hip(q,k,v,output,seq_len,&cfg{num_heads,head_dim,causal=true,scale=1/sqrt(d)})
+ * (K/rocm/attention.rs:54-65) with grouped KV heads. */
+size_t bitnet_hip_attention_prefill_workspace_bytes(size_t n_heads, size_t n_kv_heads, size_t seq_len);
+int bitnet_hip_attention_prefill_dev(const float *qkv_dev, const float *rope_sin_dev,
+                                     const float *rope_cos_dev, float *kcache_dev, float *vcache_dev,
+                                     size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                     size_t seq_len, void *workspace_dev, size_t workspace_bytes,
+                                     float *out_dev, void *stream);
 /* bytes of scratch_dev the call above needs (per-chunk softmax partials) */
 size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos);
 /* TransformerModel::logits, tied embeddings (T:1599-1630): logits = LN(x) . E^T, E the f16

@@ -1,0 +1,139 @@
+"""GPU parity of the prompt (prefill) path: causal attention over a whole prompt and the
+host-side prefill loop (tiled matmuls + attention), against the CPU oracle run token by
+token (oracle/transformer_oracle.c, T:1482-1504), and against this library's own
+single-token path (same KV cache contents, same next tokens)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def synth(pkg):
+    return importlib.import_module("bitnet-rs_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+
+    return torch
+
+
+def rope_np(x, sin, cos):
+    half = x.shape[-1] // 2
+    x0, x1 = x[..., :half], x[..., half:]
+    return np.concatenate([x0 * cos - x1 * sin, x0 * sin + x1 * cos], axis=-1)
+
+
+@pytest.mark.parametrize("T,n_heads,n_kv", [(1, 4, 2), (37, 4, 2), (64, 4, 4), (200, 20, 5), (333, 8, 2)])
+def test_prefill_attention_matches_f64_reference(hip, oracle, torch_, T, n_heads, n_kv):
+    D, max_pos = 128, 512
+    rng = np.random.default_rng(T)
+    qkv = rng.normal(0, 1.5, (T, (n_heads + 2 * n_kv) * D)).astype(np.float32)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    sin, cos = sin.reshape(max_pos, D // 2), cos.reshape(max_pos, D // 2)
+    q = qkv[:, : n_heads * D].reshape(T, n_heads, D).astype(np.float64)
+    k = qkv[:, n_heads * D:(n_heads + n_kv) * D].reshape(T, n_kv, D).astype(np.float64)
+    v = qkv[:, (n_heads + n_kv) * D:].reshape(T, n_kv, D).astype(np.float64)
+    q = rope_np(q, sin[:T, None, :], cos[:T, None, :])
+    k = rope_np(k, sin[:T, None, :], cos[:T, None, :])
+    want = np.zeros((T, n_heads, D))
+    group = n_heads // n_kv
+    mask = np.triu(np.ones((T, T), bool), 1)
+    for h in range(n_heads):
+        s = q[:, h] @ k[:, h // group].T / np.sqrt(D)
+        s[mask] = -np.inf
+        pm = np.exp(s - s.max(axis=1, keepdims=True))
+        want[:, h] = (pm / pm.sum(axis=1, keepdims=True)) @ v[:, h // group]
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    kc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    vc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    wsb = hip.attention_prefill_workspace_bytes(n_heads, n_kv, T)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    out = torch_.full((T, n_heads * D), float("nan"), device="cuda")
+    hip.attention_prefill_dev(dev(qkv), dev(sin), dev(cos), kc, vc, n_heads, n_kv, D, max_pos, T, ws, wsb, out)
+    torch_.cuda.synchronize()
+    got = out.cpu().numpy().reshape(T, n_heads, D)
+    assert not np.isnan(got).any()
+    # f16 operands: 2^-11 relative per element; outputs are averages of O(1) values
+    assert np.max(np.abs(got - want)) <= 6e-3, np.max(np.abs(got - want))
+    assert cosine(got, want) >= 0.999995
+    # the decode cache holds the exact f32 rotated k (transposed) and v
+    kt = kc.cpu().numpy().reshape(n_kv, D, max_pos)[:, :, :T]
+    assert np.allclose(kt.transpose(2, 0, 1), k, rtol=0, atol=2e-6 * np.abs(k).max())
+    assert np.array_equal(vc.cpu().numpy().reshape(n_kv, max_pos, D)[:, :T].transpose(1, 0, 2), v.astype(np.float32))
+    assert not kc.cpu().numpy().reshape(n_kv, D, max_pos)[:, :, T:].any()
+    with pytest.raises(Exception, match="KV cache overflow"):
+        hip.attention_prefill_dev(dev(qkv), dev(sin), dev(cos), kc, vc, n_heads, n_kv, D, 16 if T > 16 else 0, T, ws, wsb, out)
+
+
+SMALL = dict(hidden=512, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, ffn=1024, vocab=2048, max_pos=160, eps=1e-5, rope_theta=10000.0)
+WIDE = dict(hidden=2560, n_layers=2, n_heads=20, n_kv_heads=5, head_dim=128, ffn=6912, vocab=4096, max_pos=96, eps=1e-5, rope_theta=500000.0)
+
+
+@pytest.mark.parametrize("cfgd,n_prompt,n_new,fmt", [(SMALL, 70, 6, "qk256"), (SMALL, 21, 4, "i2s"), (WIDE, 33, 4, "qk256")])
+def test_prefill_then_decode_matches_oracle(pkg, oracle, synth, cfgd, n_prompt, n_new, fmt):
+    cfg = synth.ModelConfig(**cfgd)
+    glob = synth.make_globals(cfg)
+    if fmt == "qk256":
+        layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+        olayers = layers
+    else:  # ternary codes + 32-element block scales: the matmuls fall back to the row-by-row GEMV inside the same entry point
+        layers = [synth.make_layer(cfg, l, fmt="i2s", block=32) for l in range(cfg.n_layers)]
+        tmap = np.array([0, 1, 0, -1], np.float32)
+        olayers = []
+        for lay in layers:
+            d = {"attn_norm": lay["attn_norm"], "ffn_norm": lay["ffn_norm"], "dense": True}
+            for name, (rows, cols) in cfg.shapes().items():
+                pk = lay[name].reshape(rows, cols // 4)
+                codes = np.stack([(pk >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(rows, cols)
+                d[name] = tmap[codes] * np.repeat(lay[name + "_scales"].reshape(rows, cols // 32), 32, axis=1)
+            olayers.append(d)
+    prompt = synth.prompt(n_prompt, cfg.vocab)
+    om = oracle.OracleModel(cfg, olayers, glob, n_threads=8)
+    seq = list(prompt)
+    o_logits = []
+    for p in range(n_prompt + n_new - 1):
+        _, logits, _ = om.step(seq[p], want_logits=p >= n_prompt - 1)
+        if p >= n_prompt - 1:
+            o_logits.append(logits)
+            seq.append(oracle.argmax(logits))
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w) if fmt == "qk256" else dec.set_layer_i2s(l, w, 32)
+    dec.set_globals(glob)
+    for digits in (4, 3):
+        dec.reset()
+        dec.feed(prompt)
+        dec.prefill(n_prompt, with_logits=True, digits=digits)
+        assert dec.position() == n_prompt
+        c = cosine(dec.last_logits(), o_logits[0])
+        assert c >= 0.9999, (digits, c)
+        for i in range(1, n_new):
+            dec.run(1, with_logits=True, use_graph=True)  # decode continues on the prefilled KV cache
+            c = cosine(dec.last_logits(), o_logits[i])
+            assert c >= 0.9999, (digits, i, c)
+        assert list(dec.history(n_prompt + n_new)) == [int(t) for t in seq], digits
+    # prefill without logits + one decode step == the same state
+    dec.reset()
+    dec.feed(prompt)
+    dec.prefill(n_prompt - 1, with_logits=False)
+    assert dec.position() == n_prompt - 1
+    dec.run(1, with_logits=True, use_graph=False)
+    assert cosine(dec.last_logits(), o_logits[0]) >= 0.9999
+    # guards
+    with pytest.raises(pkg.BitNetHipError, match="fresh sequence"):
+        dec.prefill(4)
+    dec.reset()
+    with pytest.raises(pkg.BitNetHipError, match="feed"):
+        dec.prefill(4)
+    dec.close()
+    om.close()
