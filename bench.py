@@ -42,11 +42,12 @@ def build_model(pkg, synth, workload: str, layers_override: int | None):
     cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
     if layers_override:
         cfg.n_layers = layers_override
-    cfg.max_pos = 1024  # 128-token prompt + decode steps; KV cache sized for it
+    # KV cache sized for the workload: 128-token prompt + decode steps, or 4k prompt + 512 decode (c4)
+    cfg.max_pos = 4736 if workload == "c4" else 1024
     dec = pkg.HostDecoder(cfg)
     keep = None
     for l in range(cfg.n_layers):
-        if workload == "c3":
+        if workload in ("c3", "c4"):
             w = synth.make_layer(cfg, l, fmt="qk256")
             dec.set_layer_qk256(l, w)
         else:
@@ -120,7 +121,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--prompt", type=int, default=None, help="prompt length (default 128; 4096 for c4)")
+    ap.add_argument("--digits", type=int, default=3, help="c4 prefill: fixed-point digits per activation in the tiled matmuls")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
@@ -141,14 +144,24 @@ def main():
     hip = pkg.load()
     hip.init(local_rank)
 
+    global PROMPT_LEN
+    PROMPT_LEN = args.prompt or (4096 if args.workload == "c4" else 128)
     cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers)
     assert PROMPT_LEN + args.warmup + args.steps + 2 < cfg.max_pos
     prompt = synth.prompt(PROMPT_LEN, cfg.vocab)
     dec.reset()
     dec.feed(prompt)
     use_graph = not args.eager
-    dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
-    dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
+    prefill_ms = None
+    if args.workload == "c4":
+        # whole-prompt forward (tiled matmuls + causal attention), untimed warm-up pass then the reported one
+        dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
+        dec.reset()
+        dec.feed(prompt)
+        prefill_ms = dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
+    else:
+        dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
+        dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
     dec.run(args.warmup, with_logits=True, use_graph=use_graph)      # W untimed warm-up steps
 
     ev = {}
@@ -203,7 +216,8 @@ def main():
             "config": {
                 "workload": "bitnet-b1.58-2B-4T I2_S BitNet32 (ternary, 32-elem block scales), 1xMI355X, batch=1 decode, 128-token prompt"
                 if args.workload == "c2"
-                else "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt",
+                else "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt" if args.workload == "c3"
+                else f"bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, {PROMPT_LEN}-token prefill + decode",
                 "layers": cfg.n_layers,
                 "prompt_len": PROMPT_LEN,
                 "kv_len_during_timing": [PROMPT_LEN + 1 + args.warmup, PROMPT_LEN + 1 + args.warmup + args.steps],
@@ -218,6 +232,11 @@ def main():
             "per_kernel": kernel_table,
             "last_tokens": [int(t) for t in tokens[-4:]],
         }
+        if prefill_ms is not None:
+            flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
+            out["prefill"] = {"tokens": PROMPT_LEN, "ms": round(prefill_ms, 2), "tokens_per_s": round(PROMPT_LEN / prefill_ms * 1e3, 1),
+                              "digits": args.digits, "eff_TFLOPs": round(flops / prefill_ms / 1e9, 1),
+                              "note": "whole-prompt forward incl. first sampled token; I2_S projections on i8 MFMA digit planes, attention on f16 MFMA"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
         print(json.dumps(out), flush=True)

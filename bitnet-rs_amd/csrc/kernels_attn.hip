@@ -169,25 +169,53 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(512) void k_attn_combine(const float *__restrict__ scratch, int n_heads, int n_kv,
+// One workgroup per head: 8 thread groups walk the chunk records in parallel (chunk c -> group
+// c % 8), each merging (m, l, o) online; the 8 partial states meet through LDS.  Threads of a
+// group take 4 dims each (float4: one 512-byte record row per group and step).
+__global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_heads, int n_kv,
                                                       int n_chunks_max, const int *__restrict__ pos_ptr,
                                                       float *__restrict__ out) {
     const int t_k = *pos_ptr + 1;
     const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
-    const int kvh = blockIdx.x, group = n_heads / n_kv;
-    const int g = threadIdx.x >> 7, d = threadIdx.x & 127;  // 4 heads x 128 dims
-    if (g >= group) return;
+    const int kvh = blockIdx.x, g = blockIdx.y, group = n_heads / n_kv;
+    const int tid = threadIdx.x, d4 = tid & 31, part = tid >> 5;
+    __shared__ float sm[8], sl[8];
+    __shared__ __attribute__((aligned(16))) float sa[8][kD];
     const float *base = scratch + (size_t)kvh * n_chunks_max * kRec;
-    float M = -INFINITY;
-    for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, base[(size_t)c * kRec + g]);
-    float L = 0.0f, acc = 0.0f;
-    for (int c = 0; c < n_chunks; ++c) {
+    float m = -INFINITY, l = 0.0f;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int c = part; c < n_chunks; c += 8) {
         const float *rec = base + (size_t)c * kRec;
-        const float w = expf(rec[g] - M);
-        L += w * rec[kMaxGroup + g];
-        acc += w * rec[2 * kMaxGroup + g * kD + d];
+        const float mc = rec[g], lc = rec[kMaxGroup + g];
+        const float4 o = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
+        const float m_new = fmaxf(m, mc);
+        const float s_old = expf(m - m_new), s_c = expf(mc - m_new);  // m = -inf at first: s_old = 0
+        l = l * s_old + lc * s_c;
+        a.x = a.x * s_old + o.x * s_c;
+        a.y = a.y * s_old + o.y * s_c;
+        a.z = a.z * s_old + o.z * s_c;
+        a.w = a.w * s_old + o.w * s_c;
+        m = m_new;
     }
-    out[(size_t)(kvh * group + g) * kD + d] = acc / L;
+    if (d4 == 0) {
+        sm[part] = m;
+        sl[part] = l;
+    }
+    *reinterpret_cast<float4 *>(&sa[part][4 * d4]) = a;
+    __syncthreads();
+    if (tid < kD) {
+        float M = sm[0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) M = fmaxf(M, sm[p]);  // chunk 0 always exists: M is finite
+        float L = 0.0f, acc = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float w = expf(sm[p] - M);  // groups without a chunk: exp(-inf) = 0
+            L += w * sl[p];
+            acc += w * sa[p][tid];
+        }
+        out[(size_t)(kvh * group + g) * kD + tid] = acc / L;
+    }
 }
 
 size_t attn_scratch_floats(int n_kv, int max_pos) {
@@ -201,7 +229,7 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
     const int n_chunks = (max_pos + kAttnChunk - 1) / kAttnChunk;
     hipLaunchKernelGGL(k_attn_partial, dim3(n_kv, n_chunks), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
                        vcache, n_heads, n_kv, max_pos, pos_ptr, scratch);
-    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv), dim3(512), 0, stream, scratch, n_heads, n_kv, n_chunks, pos_ptr, out);
+    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_heads, n_kv, n_chunks, pos_ptr, out);
     return hipGetLastError();
 }
 
