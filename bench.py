@@ -43,11 +43,11 @@ def build_model(pkg, synth, workload: str, layers_override: int | None):
     if layers_override:
         cfg.n_layers = layers_override
     # KV cache sized for the workload: 128-token prompt + decode steps, or 4k prompt + 512 decode (c4)
-    cfg.max_pos = 4736 if workload == "c4" else 1024
+    cfg.max_pos = 4736 if workload == "c4" else 8256 if workload == "c5" else 1024
     dec = pkg.HostDecoder(cfg)
     keep = None
     for l in range(cfg.n_layers):
-        if workload in ("c3", "c4"):
+        if workload in ("c3", "c4", "c5"):
             w = synth.make_layer(cfg, l, fmt="qk256")
             dec.set_layer_qk256(l, w)
         else:
@@ -116,12 +116,59 @@ def cpu_baseline(cfg, synth):
     }
 
 
+def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
+    """BASELINE configs[4]: one 8k-token prompt, token-parallel over the ranks (zigzag chunks,
+    replicated weights, ONE all-gather of k|v per layer over RCCL; bitnet-rs_amd/prefill_parallel.py).
+    A step = the whole prompt forward incl. the first sampled token; value = prompt tokens/s."""
+    import torch
+
+    tp_mod = importlib.import_module("bitnet-rs_amd.prefill_parallel")
+    prompt = synth.prompt(PROMPT_LEN, cfg.vocab)
+    tp = tp_mod.TokenParallelPrefill(dec, hip, r.rank, r.world, digits=args.digits)
+
+    def one():
+        dec.reset()
+        dec.feed(prompt)
+        tp.run(prompt, with_logits=True)
+
+    for _ in range(max(1, args.warmup)):
+        one()
+    steps = args.steps
+    elapsed = dist_.timed_region(r, lambda: [one() for _ in range(steps)])
+    token = int(dec.history(PROMPT_LEN + 1)[PROMPT_LEN]) if r.rank == 0 else -1
+    if r.rank == 0:
+        flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
+        kv_bytes = PROMPT_LEN * 2 * cfg.n_kv_heads * cfg.head_dim * 4
+        out = {
+            "metric": "prefill tokens/sec, bitnet-b1.58-2B-4T, one prompt token-parallel over the GPUs",
+            "value": round(PROMPT_LEN * steps / elapsed, 1),
+            "unit": "tokens/s",
+            "n_gpus": r.world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": f"i8 MFMA on {args.digits}-digit fixed-point activations (projections), f16 MFMA (attention), f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {r.world}xMI355X token-parallel prefill, {PROMPT_LEN}-token prompt",
+                       "layers": cfg.n_layers, "parallelism": f"token-parallel x{r.world} (zigzag chunks), weights replicated",
+                       "collective": f"all-gather of k|v per layer: {kv_bytes} B x {cfg.n_layers} layers" if r.world > 1 else "none (1 GPU)"},
+            "eff_TFLOPs": round(flops * steps / elapsed / 1e12, 1),
+            "first_sampled_token": token,
+        }
+        print(json.dumps(out), flush=True)
+    dec.close()
+    dist_.finalize(r)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--prompt", type=int, default=None, help="prompt length (default 128; 4096 for c4)")
     ap.add_argument("--digits", type=int, default=3, help="c4 prefill: fixed-point digits per activation in the tiled matmuls")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
@@ -145,8 +192,10 @@ def main():
     hip.init(local_rank)
 
     global PROMPT_LEN
-    PROMPT_LEN = args.prompt or (4096 if args.workload == "c4" else 128)
+    PROMPT_LEN = args.prompt or {"c4": 4096, "c5": 8192}.get(args.workload, 128)
     cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers)
+    if args.workload == "c5":
+        return bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec)
     assert PROMPT_LEN + args.warmup + args.steps + 2 < cfg.max_pos
     prompt = synth.prompt(PROMPT_LEN, cfg.vocab)
     dec.reset()

@@ -127,6 +127,9 @@ class HipLib:
         L.bitnet_hip_attention_prefill_workspace_bytes.argtypes = [_sz, _sz, _sz]
         L.bitnet_hip_attention_prefill_workspace_bytes.restype = _sz
         L.bitnet_hip_attention_prefill_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]
+        L.bitnet_hip_attention_prefill_sharded_workspace_bytes.argtypes = [_sz, _sz, _sz, _sz]
+        L.bitnet_hip_attention_prefill_sharded_workspace_bytes.restype = _sz
+        L.bitnet_hip_attention_prefill_sharded_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]
         L.bitnet_hip_attention_scratch_bytes.argtypes = [_sz, _sz]
         L.bitnet_hip_attention_scratch_bytes.restype = _sz
         L.bitnet_hip_logits_f16_dev.argtypes = [_vp, _vp, _vp, C.c_float, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
@@ -269,6 +272,15 @@ class HipLib:
                               workspace_bytes, out, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_attention_prefill_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
                                                             head_dim, max_pos, seq_len, _ptr(workspace), workspace_bytes, _ptr(out), _vp(stream)))
+
+    def attention_prefill_sharded_workspace_bytes(self, n_heads: int, n_kv: int, n_q: int, n_ctx: int) -> int:
+        return int(self.c.bitnet_hip_attention_prefill_sharded_workspace_bytes(n_heads, n_kv, n_q, n_ctx))
+
+    def attention_prefill_sharded_dev(self, q, ld_q, q_block_pos, n_q, kv, ld_kv, n_ctx, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv,
+                                      head_dim, max_pos, workspace, workspace_bytes, out, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_prefill_sharded_dev(_ptr(q), ld_q, _ptr(q_block_pos), n_q, _ptr(kv), ld_kv, n_ctx, _ptr(rope_sin),
+                                                                    _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos,
+                                                                    _ptr(workspace), workspace_bytes, _ptr(out), _vp(stream)))
 
     def weights_free(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_free(h))

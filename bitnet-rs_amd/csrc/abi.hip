@@ -562,25 +562,59 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
 }
 
 size_t bitnet_hip_attention_prefill_workspace_bytes(size_t n_heads, size_t n_kv_heads, size_t seq_len) {
-    return attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len);
+    return attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len, (int)seq_len);
+}
+
+size_t bitnet_hip_attention_prefill_sharded_workspace_bytes(size_t n_heads, size_t n_kv_heads, size_t n_q, size_t n_ctx) {
+    return attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)n_q, (int)n_ctx);
+}
+
+static int check_prefill_args(const void *a, const void *b, const void *rs, const void *rc, const void *kc, const void *vc,
+                              const void *ws, const void *out, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                              size_t n_ctx) {
+    if (!a || !b || !rs || !rc || !kc || !vc || !ws || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_prefill");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim != 128) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_prefill: head_dim %zu unsupported (128)", head_dim);
+    if (n_ctx == 0 || n_ctx > max_pos)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "KV cache overflow: seq_len %zu, max_pos %zu", n_ctx, max_pos);  // T:1190-1194
+    return BITNET_HIP_OK;
 }
 
 int bitnet_hip_attention_prefill_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                                      float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                      size_t seq_len, void *workspace, size_t workspace_bytes, float *out, void *stream) {
     BH_GUARD_BEGIN
-    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !workspace || !out)
-        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_prefill_dev");
-    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)  // T:215-220
-        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
-    if (head_dim != 128) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_prefill: head_dim %zu unsupported (128)", head_dim);
-    if (seq_len == 0 || seq_len > max_pos)
-        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "KV cache overflow: seq_len %zu, max_pos %zu", seq_len, max_pos);  // T:1190-1194
-    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len);
+    int rc = check_prefill_args(qkv, qkv, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, seq_len);
+    if (rc) return rc;
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len, (int)seq_len);
     if (workspace_bytes < need)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
-    BH_HIP_TRY(launch_attn_prefill(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
-                                   (int)max_pos, (int)seq_len, workspace, workspace_bytes, out, (hipStream_t)stream));
+    const int ld = (int)((n_heads + 2 * n_kv_heads) * head_dim);
+    BH_HIP_TRY(launch_attn_prefill(qkv, ld, nullptr, (int)seq_len, qkv + n_heads * head_dim, ld, (int)seq_len, rope_sin, rope_cos, kcache,
+                                   vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes, out,
+                                   (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_attention_prefill_sharded_dev(const float *q, size_t ld_q, const int32_t *q_block_pos, size_t n_q, const float *kv,
+                                             size_t ld_kv, size_t n_ctx, const float *rope_sin, const float *rope_cos, float *kcache,
+                                             float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                             void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    int rc = check_prefill_args(q, kv, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, n_ctx);
+    if (rc) return rc;
+    if (n_q == 0 || !q_block_pos) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_sharded: n_q and q_block_pos must be given");
+    if (ld_q < n_heads * head_dim || ld_kv < 2 * n_kv_heads * head_dim)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_sharded: row strides too small (ld_q %zu, ld_kv %zu)", ld_q, ld_kv);
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)n_q, (int)n_ctx);
+    if (workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
+    BH_HIP_TRY(launch_attn_prefill(q, (int)ld_q, q_block_pos, (int)n_q, kv, (int)ld_kv, (int)n_ctx, rope_sin, rope_cos, kcache, vcache,
+                                   (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes, out,
+                                   (hipStream_t)stream));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }

@@ -31,29 +31,39 @@ constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
 constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
 
 struct PrefillArgs {
-    const float *qkv;  // [T, (heads + 2 kv) * 128]
+    const float *q;   // query rows [nq, ld_q]: head h at columns [128 h, 128 h + 128)
+    const float *kv;  // context rows [T, ld_kv] in absolute order: k heads, then v heads
+    int ld_q, ld_kv;
+    const int *q_block_pos;  // absolute position of each 64-query block (null: block b starts at 64 b)
+    int nq, nq_pad;          // query rows held here (token-parallel prefill: a subset of the prompt)
     const float *rope_sin, *rope_cos;
     float *kcache, *vcache;
-    int n_heads, n_kv, max_pos, T, Tpad;
-    _Float16 *qh, *kh, *vt;  // workspace
-    float *out;              // [T, heads * 128]
+    int n_heads, n_kv, max_pos, T, Tpad;  // T = context tokens (keys)
+    _Float16 *qh, *kh, *vt;  // workspace: q [head][nq_pad][128], k [kv][Tpad][128], v^T [kv][128][Tpad]
+    float *out;              // [nq, heads * 128]
 };
 
+// grid (max(nq_pad, Tpad) / 64, heads + 2 kv): slot < heads: query head (rows of p.q, positions from
+// q_block_pos); then k heads, then v heads (rows of p.kv, position = row).
 __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     __shared__ float tile[kQB][kPD + 1];
     const int slot = blockIdx.y, t0 = blockIdx.x * kQB, tid = threadIdx.x;
-    const int ld = (p.n_heads + 2 * p.n_kv) * kPD;
+    const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
+    const int n_rows = is_q ? p.nq : p.T;
+    if (t0 >= (is_q ? p.nq_pad : p.Tpad)) return;
+    const float *src = is_q ? p.q + (size_t)slot * kPD : p.kv + (size_t)(slot - p.n_heads) * kPD;
+    const int ld = is_q ? p.ld_q : p.ld_kv;
+    const int pos0 = is_q && p.q_block_pos ? p.q_block_pos[blockIdx.x] : t0;  // absolute position of row t0
     for (int i = 0; i < 32; ++i) {
         const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
-        tile[tok][d] = t0 + tok < p.T ? p.qkv[(size_t)(t0 + tok) * ld + (size_t)slot * kPD + d] : 0.0f;
+        tile[tok][d] = t0 + tok < n_rows ? src[(size_t)(t0 + tok) * ld + d] : 0.0f;
     }
     __syncthreads();
-    const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
     if (is_q || is_k) {
         // split-half RoPE (crates/bitnet-rope/src/lib.rs:59-93, T:134-163): pairs (j, j + 64)
         for (int i = 0; i < 16; ++i) {
             const int idx = tid + 256 * i, tok = idx >> 6, j = idx & 63;
-            const int pos = t0 + tok < p.T ? t0 + tok : 0;
+            const int pos = t0 + tok < n_rows ? pos0 + tok : 0;
             const float s = p.rope_sin[(size_t)pos * 64 + j], c = p.rope_cos[(size_t)pos * 64 + j];
             const float x0 = tile[tok][j], x1 = tile[tok][64 + j];
             tile[tok][j] = x0 * c - x1 * s;
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
         __syncthreads();
     }
     if (is_q) {
-        _Float16 *dst = p.qh + ((size_t)slot * p.Tpad + t0) * kPD;
+        _Float16 *dst = p.qh + ((size_t)slot * p.nq_pad + t0) * kPD;
         for (int i = 0; i < 32; ++i) {
             const int idx = tid + 256 * i;
             dst[idx] = (_Float16)tile[idx >> 7][idx & 127];
@@ -100,11 +110,14 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
     const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int qpos = qb * kQB + wave * 16 + c;  // this lane's query (B-operand column)
+    const int qrow = qb * kQB + wave * 16 + c;                    // this lane's query row (B-operand column)
+    const int bpos = p.q_block_pos ? p.q_block_pos[qb] : qb * kQB;  // absolute position of the block's first query
+    const int qpos = bpos + wave * 16 + c;
+    const int kt_last = (bpos + kQB - 1 < p.T ? bpos + kQB - 1 : p.T - 1) / kQB;  // last key tile any query of the block sees
     // Q^T operand: 8 consecutive dims per k-slot group, kept in registers for the whole block
     v8h qreg[4];
     {
-        const _Float16 *qp = p.qh + ((size_t)h * p.Tpad + qpos) * kPD + 8 * g;
+        const _Float16 *qp = p.qh + ((size_t)h * p.nq_pad + qrow) * kPD + 8 * g;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) qreg[ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
     }
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
     const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
 
-    for (int kt = 0; kt <= qb; ++kt) {
+    for (int kt = 0; kt <= kt_last; ++kt) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -192,9 +205,9 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
-    if (qpos < p.T) {
+    if (qrow < p.nq) {
         const float inv = 1.0f / l_run;
-        float *op = p.out + (size_t)qpos * p.n_heads * kPD + (size_t)h * kPD + 4 * g;
+        float *op = p.out + (size_t)qrow * p.n_heads * kPD + (size_t)h * kPD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             const float4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
@@ -203,18 +216,26 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     }
 }
 
-size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int T) {
-    const size_t tpad = div_ceil((size_t)T, kQB) * kQB;
-    return ((size_t)n_heads + 2 * (size_t)n_kv) * tpad * kPD * sizeof(_Float16) + 256;
+size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
+    const size_t qpad = div_ceil((size_t)nq, kQB) * kQB, tpad = div_ceil((size_t)T, kQB) * kQB;
+    return ((size_t)n_heads * qpad + 2 * (size_t)n_kv * tpad) * kPD * sizeof(_Float16) + 256;
 }
 
-hipError_t launch_attn_prefill(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache, float *vcache,
-                               int n_heads, int n_kv, int D, int max_pos, int T, void *workspace, size_t workspace_bytes,
-                               float *out, hipStream_t stream) {
-    if (D != kPD || T <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
-    if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, T)) return hipErrorInvalidValue;
+// q: nq query rows (stride ld_q floats) whose 64-row blocks sit at absolute positions q_block_pos
+// (null: 64 b); kv: T context rows in absolute order (stride ld_kv: k heads then v heads).
+hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
+                               const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
+                               int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream) {
+    if (D != kPD || T <= 0 || nq <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
+    if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, nq, T)) return hipErrorInvalidValue;
     PrefillArgs p;
-    p.qkv = qkv;
+    p.q = q;
+    p.kv = kv;
+    p.ld_q = ld_q;
+    p.ld_kv = ld_kv;
+    p.q_block_pos = q_block_pos;
+    p.nq = nq;
+    p.nq_pad = (int)(div_ceil((size_t)nq, kQB) * kQB);
     p.rope_sin = rope_sin;
     p.rope_cos = rope_cos;
     p.kcache = kcache;
@@ -226,12 +247,12 @@ hipError_t launch_attn_prefill(const float *qkv, const float *rope_sin, const fl
     p.Tpad = (int)(div_ceil((size_t)T, kQB) * kQB);
     uint8_t *ws = reinterpret_cast<uint8_t *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     p.qh = reinterpret_cast<_Float16 *>(ws);
-    p.kh = p.qh + (size_t)n_heads * p.Tpad * kPD;
+    p.kh = p.qh + (size_t)n_heads * p.nq_pad * kPD;
     p.vt = p.kh + (size_t)n_kv * p.Tpad * kPD;
     p.out = out;
-    const unsigned nb = (unsigned)(p.Tpad / kQB);
-    hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_prefill_attn, dim3(nb, (unsigned)n_heads), dim3(256), 0, stream, p);
+    const unsigned nbq = (unsigned)(p.nq_pad / kQB), nbk = (unsigned)(p.Tpad / kQB);
+    hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_prefill_attn, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

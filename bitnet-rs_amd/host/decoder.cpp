@@ -375,16 +375,9 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
                                          pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
     }
-    // hand over to the single-token state: residual stream of the last position, position counter
-    HCHK(hipMemcpyAsync(x_, pf_x_ + (N - 1) * H, H * 4, hipMemcpyDeviceToDevice, s));
-    const int32_t last = n - 1;
-    HCHK(hipMemcpyAsync(pos_, &last, 4, hipMemcpyHostToDevice, s));
-    HCHK(hipStreamSynchronize(s));  // `last` is a stack variable
-    if (with_logits) {
-        BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_,
-                                       pos_, history_, n_forced_, s));
-    } else {
-        BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+    {
+        const int rc = finish_prefill(n, pf_x_ + (N - 1) * H, with_logits);
+        if (rc) return rc;
     }
     HCHK(hipEventRecord(e1, s));
     HCHK(hipStreamSynchronize(s));
@@ -394,6 +387,38 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return 0;
+}
+
+int Decoder::finish_prefill(int n, const float *last_row, bool with_logits) {
+    // hand over to the single-token state: residual stream of the last position, position counter
+    if (n <= 0 || n > c_.max_pos - 1) {
+        err_ = "KV cache overflow";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t H = c_.hidden;
+    if (last_row) HCHK(hipMemcpyAsync(x_, last_row, H * 4, hipMemcpyDeviceToDevice, s));
+    const int32_t last = n - 1;
+    HCHK(hipMemcpyAsync(pos_, &last, 4, hipMemcpyHostToDevice, s));
+    HCHK(hipStreamSynchronize(s));  // `last` is a stack variable
+    if (with_logits && last_row) {
+        BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_,
+                                       pos_, history_, n_forced_, s));
+    } else {
+        BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+    }
+    HCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+void Decoder::layer_objects(int layer, uint64_t handles[4], void *ptrs[4]) const {
+    const Layer &L = layers_[(size_t)layer];
+    handles[0] = L.qkv, handles[1] = L.o, handles[2] = L.gateup, handles[3] = L.down;
+    ptrs[0] = L.attn_norm, ptrs[1] = L.ffn_norm, ptrs[2] = L.kcache, ptrs[3] = L.vcache;
+}
+
+void Decoder::global_objects(void *ptrs[7]) const {
+    ptrs[0] = embed_, ptrs[1] = final_norm_, ptrs[2] = rope_sin_, ptrs[3] = rope_cos_, ptrs[4] = history_, ptrs[5] = pos_, ptrs[6] = stream_;
 }
 
 int Decoder::history(int32_t *out, int n) {
@@ -535,6 +560,11 @@ int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elaps
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->prefill(n, with_logits != 0, digits, elapsed_ms);
 }
+int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits) {
+    return static_cast<Decoder *>(d)->finish_prefill(n, last_row, with_logits != 0);
+}
+void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4) { static_cast<Decoder *>(d)->layer_objects(layer, handles4, ptrs4); }
+void bitnet_host_global_objects(void *d, void **ptrs7) { static_cast<Decoder *>(d)->global_objects(ptrs7); }
 int bitnet_host_position(void *d) { return static_cast<Decoder *>(d)->position(); }
 int bitnet_host_history(void *d, int32_t *out, int n) { return static_cast<Decoder *>(d)->history(out, n); }
 int bitnet_host_last_logits(void *d, float *out) { return static_cast<Decoder *>(d)->last_logits(out); }

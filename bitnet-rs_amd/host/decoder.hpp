@@ -85,6 +85,15 @@ class Decoder {
     // with_logits samples the token after the prompt exactly as run() does for the last
     // prompt position.  digits: fixed-point digits per activation in the matmuls (2..4).
     int prefill(int n, bool with_logits, int digits, float *elapsed_ms);
+    // Tail of a prefill driven from outside (token-parallel prefill, bitnet-rs_amd/prefill_parallel.py):
+    // the KV cache already holds positions 0..n-1; last_row (device, [hidden]) is the residual stream
+    // of position n-1 or null on ranks that do not own it (then only the position counter moves).
+    int finish_prefill(int n, const float *last_row, bool with_logits);
+    // Device objects of one layer / of the model for such a driver: handles {qkv, o, gate|up, down},
+    // pointers {attn_norm, ffn_norm, kcache, vcache}; globals {embed, final_norm, rope_sin, rope_cos,
+    // history, pos, stream}.
+    void layer_objects(int layer, uint64_t handles[4], void *ptrs[4]) const;
+    void global_objects(void *ptrs[7]) const;
     int position();                                  // tokens consumed so far
     int history(int32_t *out, int n);                // first n tokens of the sequence
     int last_logits(float *out);                     // [vocab], of the last step run with logits
@@ -153,6 +162,9 @@ int bitnet_host_reset(void *d);
 int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
+int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);
+void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4);
+void bitnet_host_global_objects(void *d, void **ptrs7);
 int bitnet_host_position(void *d);
 int bitnet_host_history(void *d, int32_t *out, int n);
 int bitnet_host_last_logits(void *d, float *out);

@@ -261,7 +261,22 @@ int bitnet_hip_attention_prefill_dev(const float *qkv_dev, const float *rope_sin
                                      size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                      size_t seq_len, void *workspace_dev, size_t workspace_bytes,
                                      float *out_dev, void *stream);
-/* bytes of scratch_dev the call above needs (per-chunk softmax partials) */
+/* Token-parallel form of the call above (long prompts split over several GPUs): this GPU holds
+ * n_q of the prompt's query rows, q_dev [n_q, ld_q] (head h at columns [128 h, 128 h+128)), in
+ * 64-row blocks whose absolute first positions are q_block_pos_dev[b] (multiples of 64; only
+ * the last block may be partial), and the raw k|v rows of the WHOLE context gathered from all
+ * ranks in absolute order, kv_dev [n_ctx, ld_kv] (k heads, then v heads).  Every query attends
+ * to positions <= its own; the cache receives all n_ctx positions.  Needs no collective itself:
+ * the caller gathers k|v (RCCL all-gather) between the projection and this call. */
+size_t bitnet_hip_attention_prefill_sharded_workspace_bytes(size_t n_heads, size_t n_kv_heads, size_t n_q, size_t n_ctx);
+int bitnet_hip_attention_prefill_sharded_dev(const float *q_dev, size_t ld_q, const int32_t *q_block_pos_dev,
+                                             size_t n_q, const float *kv_dev, size_t ld_kv, size_t n_ctx,
+                                             const float *rope_sin_dev, const float *rope_cos_dev,
+                                             float *kcache_dev, float *vcache_dev, size_t n_heads,
+                                             size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                             void *workspace_dev, size_t workspace_bytes, float *out_dev,
+                                             void *stream);
+/* bytes of scratch_dev attention_decode_dev needs (per-chunk softmax partials) */
 size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos);
 /* TransformerModel::logits, tied embeddings (T:1599-1630): logits = LN(x) . E^T, E the f16
  * table [vocab, hidden], f32 accumulate; gamma_dev == NULL skips the final norm (T:1589).

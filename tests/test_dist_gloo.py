@@ -28,6 +28,8 @@ def test_two_rank_gloo_timing_and_aggregation(tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     assert [r["world"] for r in res] == [2, 2]
+    # the all-gather + scatter of the token-parallel prefill puts every k|v row at its absolute position
+    assert all(r["gather_ok"] for r in res)
     # every rank reports the SAME elapsed time = the slowest rank's (max over ranks)
     assert abs(res[0]["elapsed"] - res[1]["elapsed"]) < 1e-9
     assert res[0]["elapsed"] >= 0.1 - 1e-3  # rank 1 slept 0.1 s

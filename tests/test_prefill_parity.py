@@ -137,3 +137,45 @@ def test_prefill_then_decode_matches_oracle(pkg, oracle, synth, cfgd, n_prompt, 
         dec.prefill(4)
     dec.close()
     om.close()
+
+
+@pytest.mark.parametrize("world,T", [(1, 128), (2, 256), (4, 512)])
+def test_token_parallel_prefill_virtual_ranks(pkg, hip, synth, torch_, world, T):
+    """The sharded prompt forward (bitnet-rs_amd/prefill_parallel.py) with `world` virtual ranks
+    driven in lock-step on ONE GPU (the all-gather replaced by stacking the ranks' contributions)
+    against the unsharded Decoder.prefill: same KV cache, same logits, same next tokens."""
+    tp_mod = importlib.import_module("bitnet-rs_amd.prefill_parallel")
+    cfg = synth.ModelConfig(**dict(SMALL, max_pos=640))
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    prompt = synth.prompt(T, cfg.vocab)
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w)
+    dec.set_globals(glob)
+    # reference: one GPU does it all
+    dec.reset()
+    dec.feed(prompt)
+    dec.prefill(T, with_logits=True, digits=3)
+    want_logits = dec.last_logits()
+    dec.run(3, with_logits=True)
+    want_tokens = dec.history(T + 4)
+    # sharded
+    dec.reset()
+    dec.feed(prompt)
+    ranks = [tp_mod.TokenParallelPrefill(dec, hip, r, world, digits=3) for r in range(world)]
+    for r in ranks:
+        r.begin(prompt)
+    assert sorted(np.concatenate([tp_mod.local_positions(ranks[0].plan[r]) for r in range(world)]).tolist()) == list(range(T))
+    for l in range(cfg.n_layers):
+        gathered = torch_.stack([r.layer_front(l) for r in ranks])
+        for r in ranks:
+            r.layer_back(l, gathered)
+    ranks[0].finish(with_logits=True)
+    assert dec.position() == T
+    got_logits = dec.last_logits()
+    assert cosine(got_logits, want_logits) >= 0.999999
+    assert np.max(np.abs(got_logits - want_logits)) <= 1e-3 * np.max(np.abs(want_logits))
+    dec.run(3, with_logits=True)  # decode continues on the cache the shards filled
+    assert list(dec.history(T + 4)) == list(want_tokens)
+    dec.close()
