@@ -30,6 +30,7 @@ void free_weights(Weights *w) {
     if (w->scales) (void)hipFree(w->scales);
     if (w->tiles) (void)hipFree(w->tiles);
     if (w->scale_tiles) (void)hipFree(w->scale_tiles);
+    if (w->scale_tiles_h) (void)hipFree(w->scale_tiles_h);
     delete w;
 }
 
@@ -264,7 +265,12 @@ static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float
     w->block_size = block_size;
     w->nblk = nblk;
     w->lut = lut;
-    w->algorithmic_bytes = packed_k * n + 4 * n * nblk;
+    if (block_size == 32) {  // f16-exact scales (BitNet32-F16): keep them as f16 in the streaming layout
+        bool exact = true;
+        for (size_t i = 0; i < n * nblk && exact; ++i) exact = (float)(_Float16)scales[i] == scales[i];
+        w->scales_f16 = exact;
+    }
+    w->algorithmic_bytes = packed_k * n + (w->scales_f16 ? 2 : 4) * n * nblk;
     w->device = g_device;
     if (hipMalloc((void **)&w->codes, packed_k * n + 16) != hipSuccess ||
         hipMalloc((void **)&w->scales, 4 * n * nblk) != hipSuccess) {
@@ -458,10 +464,15 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->scales = nullptr;
     f->tiles = nullptr;
     f->scale_tiles = nullptr;
+    f->scale_tiles_h = nullptr;
+    for (Weights *w : ws) f->scales_f16 = f->scales_f16 && w->scales_f16;
     f->rows = rows;
     f->paired = interleave16 != 0;
     f->algorithmic_bytes = 0;
-    for (Weights *w : ws) f->algorithmic_bytes += w->algorithmic_bytes;
+    for (Weights *w : ws) {
+        f->algorithmic_bytes += w->algorithmic_bytes;
+        if (w->scales_f16 && !f->scales_f16) f->algorithmic_bytes += 2 * w->rows * w->nblk;  // stored as f32 in the fused matrix
+    }
     const size_t stride = f->row_stride_bytes, sstride = f->nblk * sizeof(float);
     bool ok = hipMalloc((void **)&f->codes, rows * stride + 16) == hipSuccess;
     if (ok && ws[0]->scales) ok = hipMalloc((void **)&f->scales, rows * sstride) == hipSuccess;

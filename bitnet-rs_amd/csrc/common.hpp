@@ -64,6 +64,10 @@ struct Weights {
     // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
     uint8_t *tiles = nullptr;
     float *scale_tiles = nullptr;  // 32-block scales in tile order (kernels_mfma.hip k_retile_scales)
+    // Every scale is exactly an f16 value (BitNet32-F16 files store them so): the streaming layout
+    // keeps them as f16 (2 bytes per 32 weights instead of 4) -- same numbers, fewer bytes.
+    bool scales_f16 = false;
+    uint16_t *scale_tiles_h = nullptr;
     size_t n_row_tiles = 0, n_kblocks = 0;
     bool paired = false;  // rows are interleaved (gate tile, up tile) pairs (weights_concat interleave16)
 };

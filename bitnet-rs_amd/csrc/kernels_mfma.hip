@@ -71,6 +71,7 @@ struct MfmaArgs {
     const float *residual; // optional: y = residual + W x
     const float *wscale;   // optional f32 scale per (row, 256-block)
     const float *stiles;   // optional f32 scales per (row, 32-block), tiled [tile][blk][q][cg][half][j]
+    const uint16_t *stiles_h;  // the same as f16 when every scale is an f16 value (template BS32 == 2)
     int silu_mul;          // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     unsigned long long *stamps;  // diagnostic builds only
 };
@@ -147,7 +148,7 @@ __device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &
 // UNCONDITIONAL (indices clamped, values masked afterwards), so that hipcc can count the
 // outstanding loads: with a load inside any branch it falls back to s_waitcnt vmcnt(0) at the
 // first use of the activations, i.e. waits for the whole weight stream before the prologue.
-template <int NW, int RING, int NV, bool LN, bool BS32>
+template <int NW, int RING, int NV, bool LN, int BS32>
 __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -195,17 +196,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     const uint8_t *wbase = p.tiles + ((size_t)tile * p.nblk * 64 + lane) * 16;
     // 32-element block scales ride along: 512 B per tile, 32 B per lane (8 floats: rows
     // 4q..4q+3 of 32-blocks 2*cg and 2*cg+1 of this 256-block), shared by the 4 digit lanes
-    const float *sbase = BS32 ? p.stiles + ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8 : nullptr;
+    const size_t sidx = ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8;
+    const float *sbase = BS32 == 1 ? p.stiles + sidx : nullptr;
+    const uint16_t *sbase_h = BS32 == 2 ? p.stiles_h + sidx : nullptr;
     uint4 wt[RING];
     float4 s_lo[RING], s_hi[RING];
+    uint4 s_h[RING];
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
         const int blk = b0 + j < b1 ? b0 + j : b1 - 1;  // clamped: a short range re-reads its last tile
         wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)blk * 1024);
-        if (BS32) {
+        if (BS32 == 1) {
             s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128);
             s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128 + 4);
         }
+        if (BS32 == 2) s_h[j] = *reinterpret_cast<const uint4 *>(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
     }
     BH_STAMP(1);
 
@@ -313,7 +318,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 b[3] &= bmask;
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
                 if (m & 1) {
-                    const float4 sv = m == 1 ? s_lo[j] : s_hi[j];
+                    float4 sv;
+                    if (BS32 == 2) {
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const h2 a01 = __builtin_bit_cast(h2, m == 1 ? s_h[j].x : s_h[j].z), a23 = __builtin_bit_cast(h2, m == 1 ? s_h[j].y : s_h[j].w);
+                        sv = float4{(float)a01[0], (float)a01[1], (float)a23[0], (float)a23[1]};
+                    } else {
+                        sv = m == 1 ? s_lo[j] : s_hi[j];
+                    }
                     facc[0] += (float)acc[0] * sv.x;
                     facc[1] += (float)acc[1] * sv.y;
                     facc[2] += (float)acc[2] * sv.z;
@@ -439,7 +451,9 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
     a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
-    a.stiles = (w.scales && w.block_size == 32) ? w.scale_tiles : nullptr;
+    const bool bs32_any = w.scales && w.block_size == 32;
+    a.stiles = (bs32_any && !w.scales_f16) ? w.scale_tiles : nullptr;
+    a.stiles_h = (bs32_any && w.scales_f16) ? w.scale_tiles_h : nullptr;
     a.silu_mul = fu.silu_mul ? 1 : 0;
     a.stamps = g_mfma_stamps;
     const int tiles_per_wg = nw / a.ksplit;
@@ -447,14 +461,16 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     const size_t out_rows = fu.silu_mul ? w.rows / 2 : w.rows;
     // template selection: RING = blocks per wave, NV = statistics float4 per thread
     const int ring = (int)div_ceil((size_t)a.nblk, (size_t)a.ksplit);
-    const bool ln = fu.ln_gamma != nullptr, bs32 = a.stiles != nullptr;
+    const bool ln = fu.ln_gamma != nullptr;
+    const int bs32 = a.stiles ? 1 : a.stiles_h ? 2 : 0;
+    if (bs32_any && !bs32) return hipErrorInvalidValue;
     const int nv = ln ? (int)div_ceil(w.cols / 4, (size_t)nw * 64) : 1;
     if (ring > kRing || nv > kNVMAX) return hipErrorInvalidValue;
     void (*kfn)(MfmaArgs) = nullptr;
 #define BH_PICK(NWv, RINGv, NVv)                                                                          \
     if (nw == NWv && ring <= RINGv && nv <= NVv && !kfn)                                                  \
-        kfn = ln ? (bs32 ? k_gemv_mfma<NWv, RINGv, NVv, true, true> : k_gemv_mfma<NWv, RINGv, NVv, true, false>) \
-                 : (bs32 ? k_gemv_mfma<NWv, RINGv, 1, false, true> : k_gemv_mfma<NWv, RINGv, 1, false, false>);
+        kfn = ln ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, true, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, true, 1> : k_gemv_mfma<NWv, RINGv, NVv, true, 0>) \
+                 : (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, 1, false, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, 1, false, 1> : k_gemv_mfma<NWv, RINGv, 1, false, 0>);
     BH_PICK(8, 2, 2) BH_PICK(8, 2, 4) BH_PICK(8, 3, 2) BH_PICK(8, 3, 4) BH_PICK(8, 4, 2) BH_PICK(8, 4, 4) BH_PICK(8, 5, 2) BH_PICK(8, 5, 4)
     BH_PICK(16, 2, 1) BH_PICK(16, 2, 2) BH_PICK(16, 3, 1) BH_PICK(16, 3, 2) BH_PICK(16, 4, 1) BH_PICK(16, 4, 2)
 #undef BH_PICK
@@ -526,8 +542,28 @@ __global__ void k_retile_scales(const float *__restrict__ scales, int rows, int 
     out[i] = row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * cg + half] : 0.0f;
 }
 
+__global__ void k_retile_scales_h(const float *__restrict__ scales, int rows, int nblk, uint16_t *__restrict__ out, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 3), half = (int)((i >> 2) & 1), cg = (int)((i >> 3) & 3), q = (int)((i >> 5) & 3);
+    const size_t tb = i >> 7;
+    const int blk = (int)(tb % nblk);
+    const size_t tile = tb / nblk;
+    const int row = (int)(16 * tile + 4 * q + j);
+    const _Float16 h = (_Float16)(row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * cg + half] : 0.0f);  // exact: checked at upload
+    out[i] = __builtin_bit_cast(uint16_t, h);
+}
+
 hipError_t build_tiles(Weights &w, hipStream_t stream) {
-    if (w.scales && w.block_size == 32 && !w.scale_tiles) {
+    if (w.scales && w.block_size == 32 && w.scales_f16 && !w.scale_tiles_h) {
+        const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
+        const size_t total = n_tiles * nblk * 128;
+        hipError_t e = hipMalloc((void **)&w.scale_tiles_h, total * sizeof(uint16_t));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_retile_scales_h, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, w.scales, (int)w.rows,
+                           (int)nblk, w.scale_tiles_h, total);
+    }
+    if (w.scales && w.block_size == 32 && !w.scales_f16 && !w.scale_tiles) {
         const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
         const size_t total = n_tiles * nblk * 128;
         hipError_t e = hipMalloc((void **)&w.scale_tiles, total * sizeof(float));

@@ -63,7 +63,8 @@ def ternary_weights(rows: int, cols: int, block: int, seed: int, layer: int, pro
     b = rng.integers(0, 256, rows * cols // 4, dtype=np.uint8)
     packed = (a & 0x55) | (((a & b) & 0x55) << 1)
     nblk = -(-cols // block)
-    scales = (2.0 / ((np.arange(rows * nblk) % 100) + 1)).astype(np.float32)
+    # BitNet32-F16 stores one f16 scale per 32 weights: the synthetic scales are f16 values (held as f32)
+    scales = (2.0 / ((np.arange(rows * nblk) % 100) + 1)).astype(np.float16).astype(np.float32)
     return packed.reshape(-1), scales
 
 
