@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         const int j = j0 + lane, jc = j < pos ? j : (pos > 0 ? pos - 1 : 0);
         const float *kp = kt + (size_t)(32 * wave) * max_pos + jc;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = kp[(size_t)i * max_pos];
+        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + (size_t)i * max_pos);  // cache bytes are read once per token
         // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions jj = hp, hp+2, ...
         const int d = tid & 127, hp = tid >> 7;
 #pragma unroll
         for (int i = 0; i < kAttnChunk / 2; ++i) {
             const int jj = j0 + 2 * i + hp, jcl = jj < pos ? jj : (pos > 0 ? pos - 1 : 0);
-            vv[i] = vc[(size_t)jcl * kD + d];
+            vv[i] = __builtin_nontemporal_load(vc + (size_t)jcl * kD + d);
         }
     }
     // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__
 #pragma unroll
         for (int c = 0; c < kLogitChunks; ++c)
             if (c < nchunks) {
-                const half8 a = *reinterpret_cast<const half8 *>(e0 + 512 * c);
-                const half8 b = *reinterpret_cast<const half8 *>(e1 + 512 * c);
+                // the table is read once per token by one wave: non-temporal (MI355X_MICROARCH.md, nt-weights)
+                const half8 a = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(e0 + 512 * c));
+                const half8 b = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(e1 + 512 * c));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     acc0 += xr[c][i] * (float)a[i];

@@ -38,6 +38,19 @@
 namespace bitnet_hip {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v4fl __attribute__((ext_vector_type(4)));
+
+// Weight bytes are read ONCE per launch by ONE CU: non-temporal loads keep them from displacing
+// the activation vectors in L2 / Infinity Cache and land sooner (MI355X_MICROARCH.md, nt-weights).
+__device__ __forceinline__ uint4 load_nt16(const void *p) {
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return uint4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ float4 load_nt16f(const float *p) {
+    const v4fl v = __builtin_nontemporal_load(reinterpret_cast<const v4fl *>(p));
+    return float4{v[0], v[1], v[2], v[3]};
+}
 
 // In-kernel time stamps (s_memrealtime, 100 MHz) for the diagnostic build only; the
 // production library is compiled without BH_STAMPS and carries none of this.
@@ -205,12 +218,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
         const int blk = b0 + j < b1 ? b0 + j : b1 - 1;  // clamped: a short range re-reads its last tile
-        wt[j] = *reinterpret_cast<const uint4 *>(wbase + (size_t)blk * 1024);
+        wt[j] = load_nt16(wbase + (size_t)blk * 1024);
         if (BS32 == 1) {
-            s_lo[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128);
-            s_hi[j] = *reinterpret_cast<const float4 *>(sbase + (size_t)blk * 128 + 4);
+            s_lo[j] = load_nt16f(sbase + (size_t)blk * 128);
+            s_hi[j] = load_nt16f(sbase + (size_t)blk * 128 + 4);
         }
-        if (BS32 == 2) s_h[j] = *reinterpret_cast<const uint4 *>(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
+        if (BS32 == 2) s_h[j] = load_nt16(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
     }
     BH_STAMP(1);
 
