@@ -106,6 +106,8 @@ class HipLib:
         L.bitnet_hip_matmul_i2s.argtypes = [_i8p, _sz, _u8p, _sz, _f32p, _sz, _sz, _sz, _sz]
         L.bitnet_hip_quantize.argtypes = [_f32p, _sz, _u8p, _sz, _f32p, _sz, C.c_int]
         L.bitnet_hip_dequant_i2s.argtypes = [_u8p, _sz, _sz, _sz, C.c_int, C.c_float, C.c_int, _f32p, _sz]
+        L.bitnet_hip_attention.argtypes = [_f32p, _sz, _f32p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, _sz, C.c_int, C.c_float]
+        L.bitnet_hip_qk256_gemv_batch.argtypes = [C.c_void_p, _sz]
         L.bitnet_hip_weights_upload_qk256.argtypes = [_u8p, _sz, _sz, _sz, _sz, C.POINTER(C.c_uint64)]
         L.bitnet_hip_weights_upload_i2s.argtypes = [_u8p, _sz, _f32p, _sz, _sz, _sz, _sz, C.POINTER(C.c_uint64)]
         L.bitnet_hip_weights_upload_coded.argtypes = [_u8p, _sz, _f32p, _sz, _sz, _sz, _sz, _i8p, C.POINTER(C.c_uint64)]
@@ -230,6 +232,28 @@ class HipLib:
             self.c.bitnet_hip_dequant_i2s(d.ctypes.data_as(_u8p), d.size, rows, cols, int(inv), k, int(transposed), out.ctypes.data_as(_f32p), out.size)
         )
         return out
+
+    def attention(self, q, k, v, seq_len: int, num_heads: int, head_dim: int, causal: bool = True, scale: float | None = None) -> np.ndarray:
+        qa, ka, va = _np(q, np.float32).reshape(-1), _np(k, np.float32).reshape(-1), _np(v, np.float32).reshape(-1)
+        out = np.zeros(qa.size, np.float32)
+        sc = float(scale) if scale is not None else 1.0 / float(np.sqrt(head_dim))
+        self._check(self.c.bitnet_hip_attention(qa.ctypes.data_as(_f32p), qa.size, ka.ctypes.data_as(_f32p), ka.size, va.ctypes.data_as(_f32p), va.size,
+                                                out.ctypes.data_as(_f32p), out.size, seq_len, num_heads, head_dim, int(causal), sc))
+        return out
+
+    def qk256_gemv_batch(self, items) -> list:
+        """items: (weights u8, scales f32, input f32, m, n, k) tuples -> list of outputs [m*n]."""
+        class Item(C.Structure):
+            _fields_ = [("weights", _u8p), ("weights_len", _sz), ("scales", _f32p), ("scales_len", _sz), ("input", _f32p), ("input_len", _sz),
+                        ("output", _f32p), ("output_len", _sz), ("m", _sz), ("n", _sz), ("k", _sz)]
+        keep, arr = [], (Item * len(items))()
+        for i, (w, s, x, m, n, k) in enumerate(items):
+            wa, sa, xa, ya = _np(w, np.uint8), _np(s, np.float32), _np(x, np.float32), np.zeros(m * n, np.float32)
+            keep.append((wa, sa, xa, ya))
+            arr[i] = Item(wa.ctypes.data_as(_u8p), wa.size, sa.ctypes.data_as(_f32p), sa.size, xa.ctypes.data_as(_f32p), xa.size,
+                          ya.ctypes.data_as(_f32p), ya.size, m, n, k)
+        self._check(self.c.bitnet_hip_qk256_gemv_batch(C.cast(arr, C.c_void_p), len(items)))
+        return [kp[3] for kp in keep]
 
     # -- device-resident API ------------------------------------------------
     def weights_upload_qk256(self, qs, rows, cols, row_stride_bytes) -> int:

@@ -630,6 +630,53 @@ int bitnet_hip_attention_prefill_sharded_dev(const float *q, size_t ld_q, const 
     BH_GUARD_END
 }
 
+/* K/rocm/attention.rs:54-65: q, k, v, output [batch, num_heads, seq_len, head_dim] row-major f32 (host). */
+int bitnet_hip_attention(const float *q, size_t q_len, const float *k, size_t k_len, const float *v, size_t v_len, float *output,
+                         size_t out_len, size_t seq_len, size_t num_heads, size_t head_dim, int causal, float scale) {
+    BH_GUARD_BEGIN
+    if (!q || !k || !v || !output) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention");
+    if (num_heads == 0 || head_dim == 0 || seq_len == 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: num_heads=%zu, head_dim=%zu, seq_len=%zu", num_heads, head_dim, seq_len);
+    if (head_dim != 128) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention: head_dim %zu unsupported (128)", head_dim);
+    const size_t per_batch = num_heads * seq_len * head_dim;
+    if (q_len % per_batch != 0 || q_len == 0 || k_len != q_len || v_len != q_len || out_len != q_len)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention: q/k/v/output must all hold batch * %zu elements (got %zu, %zu, %zu, %zu)",
+                         per_batch, q_len, k_len, v_len, out_len);
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t batch = q_len / per_batch, wsb = attn_prefill_workspace_bytes((int)num_heads, (int)num_heads, (int)seq_len, (int)seq_len);
+    DevBuf qd, kd, vd, od, ws;
+    if (qd.alloc(per_batch * 4) != hipSuccess || kd.alloc(per_batch * 4) != hipSuccess || vd.alloc(per_batch * 4) != hipSuccess ||
+        od.alloc(per_batch * 4) != hipSuccess || ws.alloc(wsb) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in attention");
+    for (size_t b = 0; b < batch; ++b) {
+        if (hipMemcpy(qd.p, q + b * per_batch, per_batch * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(kd.p, k + b * per_batch, per_batch * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(vd.p, v + b * per_batch, per_batch * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy H2D failed in attention");
+        hipError_t e = launch_attn_generic(qd.as<float>(), kd.as<float>(), vd.as<float>(), od.as<float>(), (int)num_heads, (int)seq_len,
+                                           causal != 0, scale, ws.p, wsb, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+        if (hipMemcpy(output + b * per_batch, od.p, per_batch * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return set_error(BITNET_HIP_ERR_GPU, "hipMemcpy D2H failed in attention");
+    }
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+/* qk256_gemv_hip_batch (K/rocm/qk256_gemv.rs:73-82): the items one after the other. */
+int bitnet_hip_qk256_gemv_batch(const bitnet_hip_gemv_item *items, size_t n_items) {
+    if (!items && n_items) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to qk256_gemv_batch");
+    for (size_t i = 0; i < n_items; ++i) {
+        const bitnet_hip_gemv_item &it = items[i];
+        const int rc = bitnet_hip_qk256_gemv(it.weights, it.weights_len, it.scales, it.scales_len, it.input, it.input_len, it.output,
+                                             it.output_len, it.m, it.n, it.k);
+        if (rc) return rc;
+    }
+    return BITNET_HIP_OK;
+}
+
 size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos) {
     return attn_scratch_floats((int)n_kv_heads, (int)max_pos) * sizeof(float);
 }

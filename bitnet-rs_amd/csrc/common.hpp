@@ -113,6 +113,8 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
                               float *scratch, float *out, hipStream_t stream);
 size_t attn_scratch_floats(int n_kv, int max_pos);
 size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T);
+hipError_t launch_attn_generic(const float *q, const float *k, const float *v, float *out, int n_heads, int seq, int causal,
+                               float scale, void *workspace, size_t workspace_bytes, hipStream_t stream);
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
                                int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream);

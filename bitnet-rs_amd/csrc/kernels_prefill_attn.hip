@@ -31,9 +31,13 @@ constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
 constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
 
 struct PrefillArgs {
-    const float *q;   // query rows [nq, ld_q]: head h at columns [128 h, 128 h + 128)
-    const float *kv;  // context rows [T, ld_kv] in absolute order: k heads, then v heads
-    int ld_q, ld_kv;
+    // element (head h, row t, dim d) of q / k / v sits at base + h * hs + t * ld + d
+    const float *q, *k, *v;
+    int ld_q, ld_kv;        // row strides (floats)
+    int hs_q, hs_kv;        // head strides (floats): 128 for [row][head][dim] rows, rows*128 for [head][row][dim]
+    int out_hs, out_ld;     // output element (h, t, d) at out + h * out_hs + t * out_ld + d
+    int rope, causal;       // apply RoPE to q and k here / causal mask
+    float scale;            // softmax scale (1/sqrt(d) in the transformer)
     const int *q_block_pos;  // absolute position of each 64-query block (null: block b starts at 64 b)
     int nq, nq_pad;          // query rows held here (token-parallel prefill: a subset of the prompt)
     const float *rope_sin, *rope_cos;
@@ -51,7 +55,8 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
     const int n_rows = is_q ? p.nq : p.T;
     if (t0 >= (is_q ? p.nq_pad : p.Tpad)) return;
-    const float *src = is_q ? p.q + (size_t)slot * kPD : p.kv + (size_t)(slot - p.n_heads) * kPD;
+    const float *src = is_q ? p.q + (size_t)slot * p.hs_q
+                     : is_k ? p.k + (size_t)(slot - p.n_heads) * p.hs_kv : p.v + (size_t)(slot - p.n_heads - p.n_kv) * p.hs_kv;
     const int ld = is_q ? p.ld_q : p.ld_kv;
     const int pos0 = is_q && p.q_block_pos ? p.q_block_pos[blockIdx.x] : t0;  // absolute position of row t0
     for (int i = 0; i < 32; ++i) {
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
         tile[tok][d] = t0 + tok < n_rows ? src[(size_t)(t0 + tok) * ld + d] : 0.0f;
     }
     __syncthreads();
-    if (is_q || is_k) {
+    if ((is_q || is_k) && p.rope) {
         // split-half RoPE (crates/bitnet-rope/src/lib.rs:59-93, T:134-163): pairs (j, j + 64)
         for (int i = 0; i < 16; ++i) {
             const int idx = tid + 256 * i, tok = idx >> 6, j = idx & 63;
@@ -85,14 +90,14 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
             dst[idx] = (_Float16)tile[idx >> 7][idx & 127];
         }
         float *kt = p.kcache + (size_t)kvh * kPD * p.max_pos;  // [128][max_pos]
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < 32 && p.kcache; ++i) {
             const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
             if (t0 + tok < p.T) kt[(size_t)d * p.max_pos + t0 + tok] = tile[tok][d];
         }
     } else {
         const int kvh = slot - p.n_heads - p.n_kv;
         float *vc = p.vcache + (size_t)kvh * p.max_pos * kPD;  // [max_pos][128]
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < 32 && p.vcache; ++i) {
             const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
             if (t0 + tok < p.T) vc[(size_t)(t0 + tok) * kPD + d] = tile[tok][d];
         }
@@ -113,7 +118,9 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     const int qrow = qb * kQB + wave * 16 + c;                    // this lane's query row (B-operand column)
     const int bpos = p.q_block_pos ? p.q_block_pos[qb] : qb * kQB;  // absolute position of the block's first query
     const int qpos = bpos + wave * 16 + c;
-    const int kt_last = (bpos + kQB - 1 < p.T ? bpos + kQB - 1 : p.T - 1) / kQB;  // last key tile any query of the block sees
+    // last key tile any query of the block sees
+    const int kt_last = p.causal ? (bpos + kQB - 1 < p.T ? bpos + kQB - 1 : p.T - 1) / kQB : (p.T - 1) / kQB;
+    const int qlim = p.causal ? qpos : p.T - 1;  // highest visible key position
     // Q^T operand: 8 consecutive dims per k-slot group, kept in registers for the whole block
     v8h qreg[4];
     {
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
-    const float scale_log2 = 1.4426950408889634f / sqrtf((float)kPD);  // softmax in base 2
+    const float scale_log2 = 1.4426950408889634f * p.scale;  // softmax in base 2
     const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
     const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
 
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pos = kt * kQB + 16 * i + 4 * g + j;
-                const float v = pos <= qpos ? s[i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470)
+                const float v = pos <= qlim ? s[i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470) / end of the context
                 s[i][j] = v;
                 mt = fmaxf(mt, v);
             }
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     l_run += __shfl_xor(l_run, 32);
     if (qrow < p.nq) {
         const float inv = 1.0f / l_run;
-        float *op = p.out + (size_t)qrow * p.n_heads * kPD + (size_t)h * kPD + 4 * g;
+        float *op = p.out + (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             const float4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
@@ -230,9 +237,16 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, nq, T)) return hipErrorInvalidValue;
     PrefillArgs p;
     p.q = q;
-    p.kv = kv;
+    p.k = kv;
+    p.v = kv + (size_t)n_kv * kPD;
     p.ld_q = ld_q;
     p.ld_kv = ld_kv;
+    p.hs_q = p.hs_kv = kPD;
+    p.out_hs = kPD;
+    p.out_ld = n_heads * kPD;
+    p.rope = 1;
+    p.causal = 1;
+    p.scale = 1.0f / sqrtf((float)kPD);
     p.q_block_pos = q_block_pos;
     p.nq = nq;
     p.nq_pad = (int)(div_ceil((size_t)nq, kQB) * kQB);
@@ -253,6 +267,43 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     const unsigned nbq = (unsigned)(p.nq_pad / kQB), nbk = (unsigned)(p.Tpad / kQB);
     hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(k_prefill_attn, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// Plain multi-head attention over caller tensors [heads][seq][128] (no RoPE, no cache): the shape of
+// the reference's fused_attention_hip stub (K/rocm/attention.rs:54-65), one batch element.
+hipError_t launch_attn_generic(const float *q, const float *k, const float *v, float *out, int n_heads, int seq, int causal,
+                               float scale, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (seq <= 0 || n_heads <= 0 || !workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_heads, seq, seq))
+        return hipErrorInvalidValue;
+    PrefillArgs p;
+    p.q = q;
+    p.k = k;
+    p.v = v;
+    p.ld_q = p.ld_kv = kPD;
+    p.hs_q = p.hs_kv = seq * kPD;
+    p.out_hs = seq * kPD;
+    p.out_ld = kPD;
+    p.rope = 0;
+    p.causal = causal;
+    p.scale = scale;
+    p.q_block_pos = nullptr;
+    p.nq = seq;
+    p.nq_pad = (int)(div_ceil((size_t)seq, kQB) * kQB);
+    p.rope_sin = p.rope_cos = nullptr;
+    p.kcache = p.vcache = nullptr;
+    p.n_heads = p.n_kv = n_heads;
+    p.max_pos = seq;
+    p.T = seq;
+    p.Tpad = p.nq_pad;
+    uint8_t *ws = reinterpret_cast<uint8_t *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    p.qh = reinterpret_cast<_Float16 *>(ws);
+    p.kh = p.qh + (size_t)n_heads * p.nq_pad * kPD;
+    p.vt = p.kh + (size_t)n_heads * p.Tpad * kPD;
+    p.out = out;
+    const unsigned nb = (unsigned)(p.nq_pad / kQB);
+    hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(3 * n_heads)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_prefill_attn, dim3(nb, (unsigned)n_heads), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -225,6 +225,23 @@ int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float 
  * K/rocm/rmsnorm.rs:50-60, host pointers: out = x / sqrt(mean(x^2)+eps) * gamma. */
 int bitnet_hip_rmsnorm(const float *input, size_t in_len, const float *gamma, size_t gamma_len,
                        float *output, size_t out_len, size_t num_rows, size_t hidden_dim, float eps);
+/* fused_attention_hip(q, k, v, output, seq_len, &HipAttentionConfig{num_heads, head_dim, causal, scale})
+ * K/rocm/attention.rs:54-65: all four tensors [batch, num_heads, seq_len, head_dim] row-major f32
+ * (batch = len / (num_heads*seq_len*head_dim)); softmax(scale * q k^T [+ causal mask]) v per head.
+ * head_dim 128 (f16 operands on the matrix cores, f32 accumulate and softmax). */
+int bitnet_hip_attention(const float *q, size_t q_len, const float *k, size_t k_len, const float *v,
+                         size_t v_len, float *output, size_t out_len, size_t seq_len, size_t num_heads,
+                         size_t head_dim, int causal, float scale);
+/* qk256_gemv_hip_batch(&[GemvBatchItem], &cfg)  K/rocm/qk256_gemv.rs:67-82: items processed in order,
+ * each with the arguments of bitnet_hip_qk256_gemv; stops at the first error. */
+typedef struct bitnet_hip_gemv_item {
+    const uint8_t *weights; size_t weights_len;
+    const float *scales;    size_t scales_len;
+    const float *input;     size_t input_len;
+    float *output;          size_t output_len;
+    size_t m, n, k;
+} bitnet_hip_gemv_item;
+int bitnet_hip_qk256_gemv_batch(const bitnet_hip_gemv_item *items, size_t n_items);
 /* Device rows: rms != 0 -> RMSNorm (above); rms == 0 -> the LayerNorm the transformer
  * actually uses (layer_norm_with_optional_bias T:67-100: no bias, mean subtracted). */
 int bitnet_hip_norm_rows_dev(const float *x_dev, const float *gamma_dev, float *out_dev, size_t rows,

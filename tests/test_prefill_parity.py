@@ -179,3 +179,43 @@ def test_token_parallel_prefill_virtual_ranks(pkg, hip, synth, torch_, world, T)
     dec.run(3, with_logits=True)  # decode continues on the cache the shards filled
     assert list(dec.history(T + 4)) == list(want_tokens)
     dec.close()
+
+
+@pytest.mark.parametrize("batch,heads,seq,causal", [(1, 2, 1, True), (2, 3, 70, True), (1, 4, 130, False)])
+def test_host_attention_dropin(hip, batch, heads, seq, causal):
+    """bitnet_hip_attention = the reference's fused_attention_hip stub signature (K/rocm/attention.rs:54-65):
+    [batch, heads, seq, head_dim] tensors, custom scale, optional causal mask; against a f64 reference."""
+    D = 128
+    rng = np.random.default_rng(seq)
+    q, k, v = (rng.normal(0, 1.2, (batch, heads, seq, D)).astype(np.float32) for _ in range(3))
+    scale = 0.11
+    s = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), k.astype(np.float64)) * scale
+    if causal:
+        s[..., np.triu(np.ones((seq, seq), bool), 1)] = -np.inf
+    pm = np.exp(s - s.max(axis=-1, keepdims=True))
+    want = np.einsum("bhqk,bhkd->bhqd", pm / pm.sum(axis=-1, keepdims=True), v.astype(np.float64))
+    got = hip.attention(q, k, v, seq, heads, D, causal=causal, scale=scale).reshape(batch, heads, seq, D)
+    assert np.max(np.abs(got - want)) <= 6e-3
+    assert cosine(got, want) >= 0.999995
+    with pytest.raises(Exception, match="head_dim 64 unsupported"):
+        hip.attention(np.zeros(8 * 64, np.float32), np.zeros(8 * 64, np.float32), np.zeros(8 * 64, np.float32), 1, 8, 64)
+    with pytest.raises(Exception, match="must all hold"):
+        hip.attention(q, k[:, :1], v, seq, heads, D)
+
+
+def test_qk256_gemv_batch_dropin(hip, oracle):
+    """qk256_gemv_hip_batch (K/rocm/qk256_gemv.rs:67-82): items in order, each = bitnet_hip_qk256_gemv."""
+    rng = np.random.default_rng(9)
+    items, wants = [], []
+    for m, n, k in ((1, 64, 256), (3, 48, 512), (2, 16, 1024)):
+        codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(n, k))
+        packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8).reshape(-1)
+        scales = rng.uniform(0.1, 1.0, n * (k // 256)).astype(np.float32)
+        x = rng.uniform(-2, 2, m * k).astype(np.float32)
+        items.append((packed, scales, x, m, n, k))
+        wants.append(oracle.i2s_matmul(x, packed, scales, m, n, k, 256))
+    outs = hip.qk256_gemv_batch(items)
+    for got, want in zip(outs, wants):
+        assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)) + 1e-6
+    with pytest.raises(Exception, match="multiple of 256"):
+        hip.qk256_gemv_batch([(np.zeros(64, np.uint8), np.ones(1, np.float32), np.zeros(100, np.float32), 1, 1, 100)])
