@@ -381,7 +381,7 @@ int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_d
         if (hipMalloc(&ws, wsb) != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed for the matmul workspace (%zu bytes)", wsb);
         hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, GemvFusion(), 4, ws, wsb, (hipStream_t)stream);
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-        hipFree(ws);
+        (void)hipFree(ws);
         if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
         return BITNET_HIP_OK;
     }

@@ -9,7 +9,10 @@
 //   k_attn_combine  grid (n_kv): out = sum_c e^(m_c-M) o_c / sum_c e^(m_c-M) l_c.
 // Same value as the reference's softmax(QK^T/sqrt(d)) V up to f32 rounding.
 //
-// Cache layout (private to this library): K transposed, kcache[n_kv][D][max_pos] (the score
+// Cache layout (private to this library): K transposed in 64-position tiles,
+// kcache[n_kv][ceil(max_pos/64)][D][64] -- one chunk's keys are 32 contiguous KB (a plain
+// [D][max_pos] transpose scatters them over 128 segments of 256 B, which HBM serves badly at
+// long contexts); element (d, pos) at ((pos / 64) * D + d) * 64 + pos % 64 (the score
 // pass reads positions contiguously: lane = position); vcache[n_kv][max_pos][D] (the P.V pass
 // reads dims contiguously: lane = dim).  *pos_ptr = number of cached tokens.
 #include "common.hpp"
@@ -21,6 +24,10 @@ constexpr int kMaxGroup = 4;
 constexpr int kD = 128;
 // per (kv head, chunk) record in the scratch buffer: m[4], l[4], o[4][128]
 constexpr int kRec = 2 * kMaxGroup + kMaxGroup * kD;
+
+// K cache element (dim d, position pos) of one KV head
+__device__ __forceinline__ size_t kidx(int d, int pos) { return ((size_t)(pos >> 6) * kD + d) * 64 + (pos & 63); }
+__host__ __device__ __forceinline__ size_t kv_head_floats(int max_pos) { return (size_t)((max_pos + 63) / 64) * 64 * kD; }
 
 template <int CTRL>
 __device__ __forceinline__ float adpp(float v) {
@@ -59,17 +66,17 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     const int group = n_heads / n_kv, half = kD / 2;
     const bool owns_new = pos >= j0 && pos < j0 + kAttnChunk;
     const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
-    float *kt = kcache + (size_t)kvh * kD * max_pos;  // [D][max_pos]
-    float *vc = vcache + (size_t)kvh * max_pos * kD;  // [max_pos][D]
+    float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos);  // [chunk][D][64]
+    float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos);  // [max_pos][D]
     // ---- every cache load of this thread is issued up front (none depends on q): the K
     //      slice for the score pass (lane = position) and the V column for the P.V pass
     //      (lane = dim); clamped addresses, masked later, so the loads are unconditional ----
     float kv[32], vv[kAttnChunk / 2];
     {
         const int j = j0 + lane, jc = j < pos ? j : (pos > 0 ? pos - 1 : 0);
-        const float *kp = kt + (size_t)(32 * wave) * max_pos + jc;
+        const float *kp = kt + kidx(32 * wave, jc);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + (size_t)i * max_pos);  // cache bytes are read once per token
+        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + (size_t)i * 64);  // cache bytes are read once per token
         // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions jj = hp, hp+2, ...
         const int d = tid & 127, hp = tid >> 7;
 #pragma unroll
@@ -98,8 +105,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             const float a = k0 * c - k1 * s, b = k0 * s + k1 * c;
             kn[tid] = a;
             kn[half + tid] = b;
-            kt[(size_t)tid * max_pos + pos] = a;  // append (transposed)
-            kt[(size_t)(half + tid) * max_pos + pos] = b;
+            kt[kidx(tid, pos)] = a;  // append (transposed)
+            kt[kidx(half + tid, pos)] = b;
         } else if (tid >= 128) {
             const float v = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid - 128)];
             vn[tid - 128] = v;

@@ -89,14 +89,16 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
             const int idx = tid + 256 * i;
             dst[idx] = (_Float16)tile[idx >> 7][idx & 127];
         }
-        float *kt = p.kcache + (size_t)kvh * kPD * p.max_pos;  // [128][max_pos]
+        // decode cache: K transposed in 64-position tiles [chunk][128][64] (kernels_attn.hip); t0 is a tile start
+        const size_t head_floats = (size_t)((p.max_pos + 63) / 64) * 64 * kPD;
+        float *kt = p.kcache + (size_t)kvh * head_floats + (size_t)(t0 >> 6) * kPD * 64;
         for (int i = 0; i < 32 && p.kcache; ++i) {
             const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
-            if (t0 + tok < p.T) kt[(size_t)d * p.max_pos + t0 + tok] = tile[tok][d];
+            if (t0 + tok < p.T) kt[(size_t)d * 64 + tok] = tile[tok][d];
         }
     } else {
         const int kvh = slot - p.n_heads - p.n_kv;
-        float *vc = p.vcache + (size_t)kvh * p.max_pos * kPD;  // [max_pos][128]
+        float *vc = p.vcache + (size_t)kvh * ((size_t)((p.max_pos + 63) / 64) * 64 * kPD);  // [max_pos][128]
         for (int i = 0; i < 32 && p.vcache; ++i) {
             const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
             if (t0 + tok < p.T) vc[(size_t)(t0 + tok) * kPD + d] = tile[tok][d];

@@ -63,7 +63,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     ok &= dalloc(&rope_sin_, (size_t)c_.max_pos * half) == hipSuccess;
     ok &= dalloc(&rope_cos_, (size_t)c_.max_pos * half) == hipSuccess;
     for (auto &L : layers_) {
-        const size_t n = (size_t)c_.n_kv_heads * c_.max_pos * D;
+        const size_t n = (size_t)c_.n_kv_heads * (((size_t)c_.max_pos + 63) / 64 * 64) * D;  // whole 64-position tiles
         ok &= dalloc(&L.kcache, n) == hipSuccess && dalloc(&L.vcache, n) == hipSuccess;
         ok &= dalloc(&L.attn_norm, H) == hipSuccess && dalloc(&L.ffn_norm, H) == hipSuccess;
     }

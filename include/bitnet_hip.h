@@ -256,7 +256,7 @@ int bitnet_hip_embed_f16_dev(const void *table_f16_dev, const int32_t *tokens_de
 int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream);
 /* One new token through MultiHeadAttention::forward's core (T:373-540): RoPE on q,k with
  * the split-half layout (T:134-163) at position *pos_dev, append k,v to the f32 cache
- * (T:1171-1202; n_kv*max_pos*head_dim floats each, layout private to this library: K is kept
+ * (T:1171-1202; n_kv*ceil(max_pos/64)*64*head_dim floats each, layout private to this library: K is kept
  * transposed), GQA softmax attention over pos+1 keys.  head_dim 128, n_heads/n_kv <= 4.
  * qkv_dev: [n_heads*D | n_kv*D | n_kv*D] raw projections; out_dev: [n_heads*D].
  * rope_sin/cos_dev: [max_pos, D/2] (crates/bitnet-rope/src/lib.rs:59-93). */

@@ -169,3 +169,45 @@ def test_decode_tokens_match_oracle(hip, pkg, oracle, synth, cfgd, n_prompt, n_n
         dec.run(cfg.max_pos, with_logits=False)
     dec.close()
     om.close()
+
+
+@pytest.mark.parametrize("max_pos,positions", [(512, [0, 63, 64, 300]), (8192, [0, 100, 3071, 3072, 5000, 8100])])
+def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions):
+    """One-token attention (RoPE + append + GQA softmax) at many context lengths against a f64 numpy
+    reference; max_pos 8192 takes the long-context form (several 64-position chunks per workgroup,
+    merged online)."""
+    n_heads, n_kv, D = 8, 2, 128
+    group = n_heads // n_kv
+    rng = np.random.default_rng(max_pos)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    kc = rng.normal(0, 1, (n_kv, D, max_pos)).astype(np.float32)   # logical [kv][D][pos]; the device keeps 64-position tiles
+    tiled = lambda a: np.ascontiguousarray(a.reshape(n_kv, D, max_pos // 64, 64).transpose(0, 2, 1, 3))
+    untiled = lambda a: a.reshape(n_kv, max_pos // 64, D, 64).transpose(0, 2, 1, 3).reshape(n_kv, D, max_pos)
+    vc = rng.normal(0, 1, (n_kv, max_pos, D)).astype(np.float32)
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a)).cuda()
+    sb = hip.c.bitnet_hip_attention_scratch_bytes(n_kv, max_pos)
+    scratch = torch_.zeros(sb // 4 + 16, device="cuda")
+    sin_d, cos_d = dev(sin), dev(cos)
+    for pos in positions:
+        qkv = rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32)
+        kcd, vcd = dev(tiled(kc)), dev(vc)
+        out = torch_.full((n_heads * D,), float("nan"), device="cuda")
+        pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
+        hip.attention_decode_dev(dev(qkv), sin_d, cos_d, kcd, vcd, n_heads, n_kv, D, max_pos, pos_d, scratch, out)
+        torch_.cuda.synchronize()
+        got = out.cpu().numpy().reshape(n_heads, D)
+        rot = lambda x: np.concatenate([x[..., :64] * cos[pos] - x[..., 64:] * sin[pos], x[..., :64] * sin[pos] + x[..., 64:] * cos[pos]], axis=-1)
+        q = rot(qkv[: n_heads * D].reshape(n_heads, D).astype(np.float64))
+        kn = rot(qkv[n_heads * D:(n_heads + n_kv) * D].reshape(n_kv, D).astype(np.float64))
+        vn = qkv[(n_heads + n_kv) * D:].reshape(n_kv, D).astype(np.float64)
+        want = np.zeros((n_heads, D))
+        for h in range(n_heads):
+            kvh = h // group
+            K = np.concatenate([kc[kvh, :, :pos].T.astype(np.float64), kn[kvh][None]], axis=0)
+            V = np.concatenate([vc[kvh, :pos].astype(np.float64), vn[kvh][None]], axis=0)
+            s = K @ q[h] / np.sqrt(D)
+            p = np.exp(s - s.max())
+            want[h] = (p / p.sum()) @ V
+        assert np.max(np.abs(got - want)) <= 2e-5 * max(1.0, np.abs(want).max()), (max_pos, pos, np.max(np.abs(got - want)))
+        # the new key / value were appended at `pos`
+        assert np.allclose(untiled(kcd.cpu().numpy())[:, :, pos], kn, atol=1e-5) and np.array_equal(vcd.cpu().numpy()[:, pos], vn.astype(np.float32))

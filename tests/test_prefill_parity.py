@@ -54,7 +54,7 @@ def test_prefill_attention_matches_f64_reference(hip, oracle, torch_, T, n_heads
         pm = np.exp(s - s.max(axis=1, keepdims=True))
         want[:, h] = (pm / pm.sum(axis=1, keepdims=True)) @ v[:, h // group]
     dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
-    kc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    kc = torch_.zeros(n_kv * max_pos * D, device="cuda")  # max_pos is a multiple of 64 here
     vc = torch_.zeros(n_kv * max_pos * D, device="cuda")
     wsb = hip.attention_prefill_workspace_bytes(n_heads, n_kv, T)
     ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
@@ -67,10 +67,11 @@ def test_prefill_attention_matches_f64_reference(hip, oracle, torch_, T, n_heads
     assert np.max(np.abs(got - want)) <= 6e-3, np.max(np.abs(got - want))
     assert cosine(got, want) >= 0.999995
     # the decode cache holds the exact f32 rotated k (transposed) and v
-    kt = kc.cpu().numpy().reshape(n_kv, D, max_pos)[:, :, :T]
-    assert np.allclose(kt.transpose(2, 0, 1), k, rtol=0, atol=2e-6 * np.abs(k).max())
+    # K cache: transposed in 64-position tiles [kv][chunk][D][64]  ->  [kv][D][max_pos]
+    k_full = kc.cpu().numpy().reshape(n_kv, max_pos // 64, D, 64).transpose(0, 2, 1, 3).reshape(n_kv, D, max_pos)
+    assert np.allclose(k_full[:, :, :T].transpose(2, 0, 1), k, rtol=0, atol=2e-6 * np.abs(k).max())
     assert np.array_equal(vc.cpu().numpy().reshape(n_kv, max_pos, D)[:, :T].transpose(1, 0, 2), v.astype(np.float32))
-    assert not kc.cpu().numpy().reshape(n_kv, D, max_pos)[:, :, T:].any()
+    assert not k_full[:, :, T:].any()
     with pytest.raises(Exception, match="KV cache overflow"):
         hip.attention_prefill_dev(dev(qkv), dev(sin), dev(cos), kc, vc, n_heads, n_kv, D, 16 if T > 16 else 0, T, ws, wsb, out)
 
