@@ -185,12 +185,24 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     const int c = lane & 15, g = lane >> 4, rw = wave & 3, cw = wave >> 2;
     const int n_tiles = (p.rows + 15) >> 4;
     const int kp = p.nblk * 256;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that one XCD
+    // works through CONSECUTIVE logical ids: the workgroups that share an activation tile (same by, all bx)
+    // then find it in ONE L2 instead of pulling it into eight.  Placement only changes speed, never results.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if ((total & 7) == 0) {
+            const int l = (id & 7) * (total >> 3) + (id >> 3);
+            bx = l % gx;
+            by = l / gx;
+        }
+    }
 
     // this wave's four weight row tiles (clamped: surplus tiles recompute the last one, never stored)
     const uint8_t *wptr[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        int t = blockIdx.x * 16 + rw * 4 + rt;
+        int t = bx * 16 + rw * 4 + rt;
         t = t < n_tiles ? t : n_tiles - 1;
         wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
     }
@@ -200,17 +212,24 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int idx = tid + 512 * i, col = idx >> 4, seg = idx & 15;
-        bsrc[i] = p.planes + (size_t)(blockIdx.y * WG_COLS + col) * kp + seg * 16;
+        bsrc[i] = p.planes + (size_t)(by * WG_COLS + col) * kp + seg * 16;
         bdst[i] = col * kColStride + seg * 16;
     }
+    constexpr int kBuf = WG_COLS * kColStride;  // one activation tile in LDS; the unscaled variant keeps two
     uint4 wn[4], bn[NB];
     if (!WS) {
+        // prologue: activation tile 0 -> LDS buffer 0, tile 1's loads in flight; weights of step 0 in flight
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt]);
 #pragma unroll
         for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
+        const int n1 = p.nblk > 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n1 * 256);
+        __syncthreads();
     }
-
     v4i acc[4][CT];
     float facc[WS ? 4 : 1][WS ? TTW : 1][4];
 #pragma unroll
@@ -228,47 +247,57 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     const uint8_t *bread = lds + (cw * CT * 16 + c) * kColStride + 64 * g;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
-        uint4 wt[4];
-        if (WS) {  // scaled variant: registers go to the f32 accumulators, no prefetch
+        const uint8_t *bcur = bread;
+        if (WS) {  // scaled variant: registers go to the f32 accumulators: single buffer, no prefetch
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)blk * 1024);
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)blk * 256);
+            __syncthreads();  // the previous step's LDS reads are done
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
+            __syncthreads();
+        } else {
+            // tile blk is in buffer blk & 1 (everyone passed the barrier that ended step blk - 1, so nobody still
+            // reads the other buffer): stage tile blk + 1 there now, then start the loads of tile blk + 2
+            bcur = bread + (blk & 1) * kBuf;
+            uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
+            if (blk + 1 < p.nblk) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(nxt + bdst[i]) = bn[i];
+            }
         }
+        uint4 wc[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) wt[rt] = wn[rt];
-        __syncthreads();  // the previous step's LDS reads are done
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
-        __syncthreads();
+        for (int rt = 0; rt < 4; ++rt) wc[rt] = wn[rt];
         if (!WS) {
-            // next step's loads fly during this step's MFMAs (clamped on the last step)
-            const int nx = blk + 1 < p.nblk ? blk + 1 : blk;
+            const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)nx * 1024);
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)n1 * 1024);  // next step's weights
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)nx * 256);
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n2 * 256);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             v4i a[4];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                const uint32_t wd = m == 0 ? wt[rt].x : m == 1 ? wt[rt].y : m == 2 ? wt[rt].z : wt[rt].w;
+                const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
                 a[rt] = gdecode16(wd, p.lut);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const v4i b = *reinterpret_cast<const v4i *>(bread + ct * 16 * kColStride + 16 * m);
+                const v4i b = *reinterpret_cast<const v4i *>(bcur + ct * 16 * kColStride + 16 * m);
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
             }
         }
+        if (!WS) __syncthreads();  // every wave is done with buffer blk & 1
         if (WS) {
             // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                int t = blockIdx.x * 16 + rw * 4 + rt;
+                int t = bx * 16 + rw * 4 + rt;
                 t = t < n_tiles ? t : n_tiles - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     // ---- epilogue: digits -> f32, x 2^(E_t - S), [residual | silu*mul], store ------------------
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
-        const int token = (blockIdx.y * 2 * TTW + cw * TTW + tt) * 16 + c;
+        const int token = (by * 2 * TTW + cw * TTW + tt) * 16 + c;
         if (token >= p.m) continue;
         const float is = p.inv_scale[token];
         float val[4][4];
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
         if (!p.silu_mul) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                const int row0 = 16 * (blockIdx.x * 16 + rw * 4 + rt) + 4 * g;
+                const int row0 = 16 * (bx * 16 + rw * 4 + rt) + 4 * g;
                 const size_t off = (size_t)token * p.rows + row0;
                 if (row0 + 3 < p.rows && (p.rows & 3) == 0) {
                     float4 o = {val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
             const int half_rows = p.rows >> 1;
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const int row0 = 16 * (blockIdx.x * 8 + rw * 2 + pr) + 4 * g;
+                const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
                 const size_t off = (size_t)token * half_rows + row0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -354,7 +383,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
     void (*gk)(GemmArgs) = a.wscale ? k_gemm_mfma<NDIG, TTWS, true> : k_gemm_mfma<NDIG, TTW, false>;
     const int ttw = a.wscale ? TTWS : TTW;
-    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride;
+    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (a.wscale ? 1 : 2);  // unscaled variant: double-buffered
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
