@@ -119,6 +119,7 @@ class HipLib:
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
+        L.bitnet_hip_weights_bind_ln.argtypes = [C.c_uint64, _vp, _vp]
         L.bitnet_hip_weights_concat.argtypes = [C.POINTER(C.c_uint64), _sz, C.c_int, C.POINTER(C.c_uint64)]
         L.bitnet_hip_gemv_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, _vp]
         L.bitnet_hip_rmsnorm.argtypes = [_f32p, _sz, _f32p, _sz, _f32p, _sz, _sz, _sz, C.c_float]
@@ -305,6 +306,9 @@ class HipLib:
         self._check(self.c.bitnet_hip_attention_prefill_sharded_dev(_ptr(q), ld_q, _ptr(q_block_pos), n_q, _ptr(kv), ld_kv, n_ctx, _ptr(rope_sin),
                                                                     _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos,
                                                                     _ptr(workspace), workspace_bytes, _ptr(out), _vp(stream)))
+
+    def weights_bind_ln(self, h: int, ln_gamma, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_weights_bind_ln(h, _ptr(ln_gamma), _vp(stream)))
 
     def weights_free(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_free(h))

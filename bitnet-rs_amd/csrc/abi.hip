@@ -31,6 +31,7 @@ void free_weights(Weights *w) {
     if (w->tiles) (void)hipFree(w->tiles);
     if (w->scale_tiles) (void)hipFree(w->scale_tiles);
     if (w->scale_tiles_h) (void)hipFree(w->scale_tiles_h);
+    if (w->ln_g) (void)hipFree(w->ln_g);
     delete w;
 }
 
@@ -440,6 +441,24 @@ int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float 
     BH_GUARD_END
 }
 
+int bitnet_hip_weights_bind_ln(bitnet_hip_weights_t h, const float *ln_gamma_dev, void *stream) {
+    BH_GUARD_BEGIN
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!ln_gamma_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_bind_ln");
+    if (!mfma_supported(*w)) return BITNET_HIP_OK;  // other kernels keep the prologue form
+    if (!w->ln_g && hipMalloc((void **)&w->ln_g, w->rows * sizeof(float)) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in weights_bind_ln");
+    w->ln_gamma_bound = nullptr;
+    hipError_t e = build_tiles(*w, (hipStream_t)stream);
+    if (e == hipSuccess) e = launch_gemv_mfma(*w, ln_gamma_dev, w->ln_g, 1, GemvFusion(), (hipStream_t)stream);  // g = W . gamma, stored row order
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "weights_bind_ln failed: %s", hipGetErrorString(e));
+    w->ln_gamma_bound = ln_gamma_dev;
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts, int interleave16,
                               bitnet_hip_weights_t *out) {
     BH_GUARD_BEGIN
@@ -465,6 +484,8 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->tiles = nullptr;
     f->scale_tiles = nullptr;
     f->scale_tiles_h = nullptr;
+    f->ln_g = nullptr;
+    f->ln_gamma_bound = nullptr;
     for (Weights *w : ws) f->scales_f16 = f->scales_f16 && w->scales_f16;
     f->rows = rows;
     f->paired = interleave16 != 0;

@@ -70,6 +70,10 @@ struct Weights {
     uint16_t *scale_tiles_h = nullptr;
     size_t n_row_tiles = 0, n_kblocks = 0;
     bool paired = false;  // rows are interleaved (gate tile, up tile) pairs (weights_concat interleave16)
+    // bitnet_hip_weights_bind_ln: g_r = W[r,:] . gamma for ONE LayerNorm weight vector (device pointer it was
+    // computed from): lets the fused LayerNorm -> GEMV apply the normalisation after the product
+    float *ln_g = nullptr;
+    const float *ln_gamma_bound = nullptr;
 };
 
 // Optional work fused around a GEMV launch (MFMA kernel only).

@@ -80,6 +80,7 @@ struct MfmaArgs {
     const float *x;        // [mt, cols]
     float *y;              // [mt, rows]  (silu_mul: [mt, rows/2])
     const float *ln_gamma; // optional LayerNorm prologue (T:67-100 semantics)
+    const float *ln_g;     // LN == 2: g_r = W[r,:] . gamma  (bitnet_hip_weights_bind_ln)
     float ln_eps;
     const float *residual; // optional: y = residual + W x
     const float *wscale;   // optional f32 scale per (row, 256-block)
@@ -161,7 +162,13 @@ __device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &
 // UNCONDITIONAL (indices clamped, values masked afterwards), so that hipcc can count the
 // outstanding loads: with a load inside any branch it falls back to s_waitcnt vmcnt(0) at the
 // first use of the activations, i.e. waits for the whole weight stream before the prologue.
-template <int NW, int RING, int NV, bool LN, int BS32>
+// LN: 0 none; 1 LayerNorm prologue on the activations; 2 the same LayerNorm applied AFTER the
+// product: with g_r = sum_k W[r,k] gamma[k] precomputed once per (matrix, gamma)
+// (bitnet_hip_weights_bind_ln),  sum_k W[r,k] (x_k - mean)/denom gamma_k = (sum_k W[r,k] gamma_k x_k - mean g_r) / denom,
+// so the waves quantise gamma*x of their own K range straight away and the row statistics are only
+// needed in the epilogue, behind the barrier that is there anyway (saves the two prologue barriers,
+// the normalised row's LDS round trip and ~1.4 us per launch).
+template <int NW, int RING, int NV, int LN, int BS32>
 __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -185,8 +192,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 
     // ---- 1. activations first (vmcnt retires in order; these come from L2) ---------------
     float4 xr[RING];
-    float4 sx[NV], sg[NV];
-    if (LN) {
+    float4 sx[NV], sg[NV], gr[LN == 2 ? RING : 1];
+    if (LN == 1) {
         // LayerNorm needs the whole row: the workgroup reads x and gamma ONCE (each thread its
         // share) and hands the normalised row to the waves through LDS.
 #pragma unroll
@@ -195,6 +202,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             const int ci = idx < nvec ? idx : nvec - 1;
             sx[i] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
             sg[i] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
+        }
+    } else if (LN == 2) {
+        // own K range of x and gamma (they gate the quantisation) and this thread's share of the whole row
+        // for the statistics (only needed in the epilogue); all ahead of the weight stream
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int idx = (b0 + j) * 64 + lane;
+            const int ci = idx < nvec ? idx : nvec - 1;
+            xr[j] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+            gr[j] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + NT * i;
+            sx[i] = *reinterpret_cast<const float4 *>(p.x + 4 * (idx < nvec ? idx : nvec - 1));
         }
     } else {
 #pragma unroll
@@ -228,7 +250,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     BH_STAMP(1);
 
     // ---- 3. prologue: [LayerNorm] -> fixed point -> this wave's digit planes --------------
-    if (LN) {
+    if (LN == 2) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            xr[j].x *= gr[j].x;
+            xr[j].y *= gr[j].y;
+            xr[j].z *= gr[j].z;
+            xr[j].w *= gr[j].w;
+        }
+    }
+    if (LN == 1) {
         // LayerNorm without bias, WITH mean subtraction (T:89-97; candle LayerNorm slow path):
         // (x - mean) / sqrt(mean((x - mean)^2) + eps) * gamma.  One pass: sum and sum of
         // squares in f64 (products of f32 are exact in f64).
@@ -369,6 +400,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     }
     BH_STAMP(4);
 
+    if (LN == 2) {
+        // row statistics, off the critical path: their loads were the first ones issued, the sums are only
+        // read behind the epilogue's barrier
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool in = tid + NT * i < nvec;
+            const double a = in ? sx[i].x : 0.0f, b = in ? sx[i].y : 0.0f, c = in ? sx[i].z : 0.0f, d = in ? sx[i].w : 0.0f;
+            s1 += (a + b) + (c + d);
+            s2 += (a * a + b * b) + (c * c + d * d);
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane == 0) {
+            stat[2 * wave] = s1;
+            stat[2 * wave + 1] = s2;
+        }
+    }
     // ---- 5. epilogue: digits -> f32 (x this wave's 2^(E-29)), K-range reduction, store -----
     const float cw = (BS32 || r16 < 4) ? __uint_as_float((uint32_t)(127 + 8 * (r16 & 3)) << 23) * inv_s : 0.0f;
     float f[4];
@@ -387,6 +436,19 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         for (int j = 0; j < 4; ++j) part[wave * 16 + 4 * g + j] = f[j];
     }
     __syncthreads();
+    double ln_mean = 0.0, ln_denom = 1.0;
+    if (LN == 2) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            s1 += stat[2 * w];
+            s2 += stat[2 * w + 1];
+        }
+        const double mean_d = s1 / (double)p.cols;
+        const double var_d = s2 / (double)p.cols - mean_d * mean_d;
+        ln_mean = (double)(float)mean_d;                                              // the f32 mean the prologue form subtracts
+        ln_denom = (double)sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+    }
     if (!p.silu_mul) {
         if (tid < tiles_per_wg * 16) {
             const int tl = tid >> 4, r = tid & 15;
@@ -394,6 +456,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             if (row < p.rows) {
                 float v = 0.0f;
                 for (int kp = 0; kp < p.ksplit; ++kp) v += part[(tl * p.ksplit + kp) * 16 + r];
+                if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) / ln_denom);
                 if (p.residual) v += p.residual[row];
                 p.y[row] = v;
             }
@@ -410,6 +473,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 for (int kp = 0; kp < p.ksplit; ++kp) {
                     gv += part[((2 * pl) * p.ksplit + kp) * 16 + r];
                     uv += part[((2 * pl + 1) * p.ksplit + kp) * 16 + r];
+                }
+                if (LN == 2) {  // stored rows: (gate tile, up tile) pairs
+                    const int t0 = blockIdx.x * tiles_per_wg + 2 * pl;
+                    gv = (float)(((double)gv - ln_mean * (double)p.ln_g[16 * t0 + r]) / ln_denom);
+                    uv = (float)(((double)uv - ln_mean * (double)p.ln_g[16 * (t0 + 1) + r]) / ln_denom);
                 }
                 p.y[row] = gv / (1.0f + expf(-gv)) * uv;
             }
@@ -463,6 +531,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
+    a.ln_g = (fu.ln_gamma && w.ln_g && w.ln_gamma_bound == fu.ln_gamma) ? w.ln_g : nullptr;
     a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
     const bool bs32_any = w.scales && w.block_size == 32;
     a.stiles = (bs32_any && !w.scales_f16) ? w.scale_tiles : nullptr;
@@ -474,7 +543,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     const size_t out_rows = fu.silu_mul ? w.rows / 2 : w.rows;
     // template selection: RING = blocks per wave, NV = statistics float4 per thread
     const int ring = (int)div_ceil((size_t)a.nblk, (size_t)a.ksplit);
-    const bool ln = fu.ln_gamma != nullptr;
+    const bool ln = fu.ln_gamma != nullptr, ln2 = a.ln_g != nullptr;
     const int bs32 = a.stiles ? 1 : a.stiles_h ? 2 : 0;
     if (bs32_any && !bs32) return hipErrorInvalidValue;
     const int nv = ln ? (int)div_ceil(w.cols / 4, (size_t)nw * 64) : 1;
@@ -482,15 +551,16 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     void (*kfn)(MfmaArgs) = nullptr;
 #define BH_PICK(NWv, RINGv, NVv)                                                                          \
     if (nw == NWv && ring <= RINGv && nv <= NVv && !kfn)                                                  \
-        kfn = ln ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, true, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, true, 1> : k_gemv_mfma<NWv, RINGv, NVv, true, 0>) \
-                 : (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, 1, false, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, 1, false, 1> : k_gemv_mfma<NWv, RINGv, 1, false, 0>);
+        kfn = ln2 ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, 2, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, 2, 1> : k_gemv_mfma<NWv, RINGv, NVv, 2, 0>) \
+              : ln ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, 1, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, 1, 1> : k_gemv_mfma<NWv, RINGv, NVv, 1, 0>) \
+                   : (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, 1, 0, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, 1, 0, 1> : k_gemv_mfma<NWv, RINGv, 1, 0, 0>);
     BH_PICK(8, 2, 2) BH_PICK(8, 2, 4) BH_PICK(8, 3, 2) BH_PICK(8, 3, 4) BH_PICK(8, 4, 2) BH_PICK(8, 4, 4) BH_PICK(8, 5, 2) BH_PICK(8, 5, 4)
     BH_PICK(16, 2, 1) BH_PICK(16, 2, 2) BH_PICK(16, 3, 1) BH_PICK(16, 3, 2) BH_PICK(16, 4, 1) BH_PICK(16, 4, 2)
 #undef BH_PICK
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;  // the instantiated RING (LDS plane stride)
     const size_t lds = (size_t)nw * 4 * (ring_t * 256 + 16) + 2 * nw * sizeof(double) + nw * 16 * sizeof(float) +
-                       (ln ? w.cols * sizeof(float) : 0);
+                       ((ln && !ln2) ? w.cols * sizeof(float) : 0);
     if (lds > 64 * 1024) {
         static std::unordered_set<const void *> raised;  // raised once per kernel, outside any capture
         if (!raised.count((const void *)kfn)) {

@@ -133,6 +133,8 @@ int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
         b += ab;
     }
     weight_bytes_ += b;
+    BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
+    BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
     return 0;
 }
 
@@ -159,6 +161,9 @@ int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
         bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
         weight_bytes_ += ab;
     }
+    // LayerNorm applied after the product for the two normalised projections (bitnet_hip_weights_bind_ln)
+    BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
+    BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
     return 0;
 }
 
@@ -194,6 +199,9 @@ int Decoder::set_layer_specs(int layer, const float *attn_norm, const float *ffn
         bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
         weight_bytes_ += ab;
     }
+    // LayerNorm applied after the product for the two normalised projections (bitnet_hip_weights_bind_ln)
+    BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
+    BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
     return 0;
 }
 

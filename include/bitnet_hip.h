@@ -216,6 +216,11 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
 int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                               const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
                               int flags, void *stream);
+/* Optional, once per (matrix, LayerNorm weight) pair: precomputes g_r = W[r,:] . gamma so that
+ * gemv_fused_dev called with THIS ln_gamma_dev pointer applies the LayerNorm after the product,
+ * (W (gamma*x) - mean g) / denom -- same value to f32 rounding, ~1.4 us less per launch (no
+ * whole-row pass before the weights can be used).  Re-bind if the gamma buffer's contents change. */
+int bitnet_hip_weights_bind_ln(bitnet_hip_weights_t w, const float *ln_gamma_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* 3. decode-step operators (device pointers; K/rocm/rmsnorm.rs, attention.rs) */

@@ -211,3 +211,47 @@ def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions):
         assert np.max(np.abs(got - want)) <= 2e-5 * max(1.0, np.abs(want).max()), (max_pos, pos, np.max(np.abs(got - want)))
         # the new key / value were appended at `pos`
         assert np.allclose(untiled(kcd.cpu().numpy())[:, :, pos], kn, atol=1e-5) and np.array_equal(vcd.cpu().numpy()[:, pos], vn.astype(np.float32))
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "ternary32"])
+def test_layernorm_after_product_matches_prologue_form(hip, oracle, torch_, fmt):
+    """bitnet_hip_weights_bind_ln: (W (gamma*x) - mean * W gamma) / denom == W LN(x) -- against the oracle
+    chain and against the prologue form, incl. an activation row with a large mean (cancellation)."""
+    rng = np.random.default_rng(5)
+    K, N = 2560, 768
+    g = (rng.uniform(0.5, 1.5, K) / 80).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    if fmt == "qk256":
+        stride = K // 256 * 64
+        q = rng.integers(0, 256, N * stride, dtype=np.uint8)
+        h = hip.weights_upload_qk256(q, N, K, stride)
+        ref = lambda xn: oracle.gemv_qk256(q, xn, N, K, stride)
+    else:
+        codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(N, K), p=[0.5, 0.25, 0.25])
+        packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8).reshape(-1)
+        scales = (2.0 / ((np.arange(N * (K // 32)) % 100) + 1)).astype(np.float16).astype(np.float32)
+        h = hip.weights_upload_i2s(packed, scales, N, K, 32)
+        ref = lambda xn: oracle.i2s_matmul(xn, packed, scales, 1, N, K, 32)
+    res = rng.normal(0, 1, N).astype(np.float32)
+    rd = torch_.from_numpy(res).cuda()
+    for mean in (0.1, 40.0):
+        x = rng.normal(mean, 1.0, K).astype(np.float32)
+        xd = torch_.from_numpy(x).cuda()
+        want = ref(oracle.layernorm(x, g, 1e-5)) + res
+        y1 = torch_.empty(N, device="cuda")
+        hip.gemv_fused_dev(h, xd, y1, 1, ln_gamma=gd, ln_eps=1e-5, residual=rd)  # prologue form (nothing bound yet / other gamma)
+        torch_.cuda.synchronize()
+        hip.weights_bind_ln(h, gd)
+        y2 = torch_.empty(N, device="cuda")
+        hip.gemv_fused_dev(h, xd, y2, 1, ln_gamma=gd, ln_eps=1e-5, residual=rd)  # LayerNorm after the product
+        g2 = gd.clone()
+        y3 = torch_.empty(N, device="cuda")
+        hip.gemv_fused_dev(h, xd, y3, 1, ln_gamma=g2, ln_eps=1e-5, residual=rd)  # a different gamma buffer: prologue form again
+        torch_.cuda.synchronize()
+        # the large-mean row loses log2(mean/std) bits in BOTH forms (f32 x - mean); the after-product form adds W.(gamma x) rounding
+        tol = (3e-5 if mean < 1 else 2e-3) * np.max(np.abs(want)) + 1e-6
+        for y in (y1, y2, y3):
+            assert np.max(np.abs(y.cpu().numpy() - want)) <= tol, (fmt, mean)
+        assert np.array_equal(y1.cpu().numpy(), y3.cpu().numpy())
+        hip.weights_bind_ln(h, g2)  # unbind for the next round: gd no longer matches
+    hip.weights_free(h)
