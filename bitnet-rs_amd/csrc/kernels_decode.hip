@@ -6,6 +6,8 @@
 //
 // Position and token live in device memory (pos_ptr / token_ptr) so one captured
 // hipGraph replays for every decode step without host round trips.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace bitnet_hip {
@@ -101,6 +103,10 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
 // each lane keeps its slice of LN(x) in registers (hidden <= 8192).
 constexpr int kLogitChunks = 16;  // 512 columns each
 
+// NCH = hidden / 512 (compile time: the activation slice lives in NCH*8 registers), R = vocabulary rows
+// per wave iteration (R * hidden * 2 bytes in flight per wave).
+// GUARD: hidden / 512 may be smaller than NCH (generic instance), chunks past it are skipped.
+template <int NCH, int R, bool GUARD = false>
 __global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__ table, const float *__restrict__ x,
                                                     const float *__restrict__ gamma, float eps, int hidden, int vocab,
                                                     float *__restrict__ logits, float *__restrict__ best_val,
@@ -122,55 +128,50 @@ __global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__
     const float denom = gamma ? sqrtf(bsum(ss, slot) / (float)hidden + eps) : 1.0f;
     for (int i = tid; i < hidden; i += 256) xs[i] = gamma ? (x[i] - mean) / denom * gamma[i] : x[i];
     __syncthreads();
-    const int nchunks = hidden >> 9;  // 512 columns per chunk (hidden % 512 == 0)
-    float xr[kLogitChunks][8];
+    const int nchunks = hidden >> 9;
+    float xr[NCH][8];
 #pragma unroll
-    for (int c = 0; c < kLogitChunks; ++c)
-        if (c < nchunks) {
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xr[c][i] = xs[512 * c + 8 * lane + i];
-        }
+        for (int i = 0; i < 8; ++i) xr[c][i] = (!GUARD || c < nchunks) ? xs[512 * c + 8 * lane + i] : 0.0f;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     const int total_waves = gridDim.x * 4;
-    // two vocabulary rows per wave iteration: 2 x hidden x 2 B in flight per wave
-    for (int row = (blockIdx.x * 4 + wave) * 2; row < vocab; row += total_waves * 2) {
-        const bool two = row + 1 < vocab;
-        const _Float16 *e0 = table + (size_t)row * hidden + 8 * lane;
-        const _Float16 *e1 = table + (size_t)(two ? row + 1 : row) * hidden + 8 * lane;
-        float acc0 = 0.0f, acc1 = 0.0f;
+    for (int row = (blockIdx.x * 4 + wave) * R; row < vocab; row += total_waves * R) {
+        half8 w[R][NCH];
 #pragma unroll
-        for (int c = 0; c < kLogitChunks; ++c)
-            if (c < nchunks) {
-                // the table is read once per token by one wave: non-temporal (MI355X_MICROARCH.md, nt-weights)
-                const half8 a = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(e0 + 512 * c));
-                const half8 b = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(e1 + 512 * c));
+        for (int r = 0; r < R; ++r) {
+            // the table is read once per token by one wave: non-temporal (MI355X_MICROARCH.md, nt-weights);
+            // rows past the end re-read the last row (never stored)
+            const _Float16 *e = table + (size_t)(row + r < vocab ? row + r : vocab - 1) * hidden + 8 * lane;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc0 += xr[c][i] * (float)a[i];
-                    acc1 += xr[c][i] * (float)b[i];
-                }
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            acc0 += __shfl_xor(acc0, off, 64);
-            acc1 += __shfl_xor(acc1, off, 64);
+            for (int c = 0; c < NCH; ++c)
+                w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(e + 512 * ((!GUARD || c < nchunks) ? c : 0)));
         }
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[r] += xr[c][i] * (float)w[r][c][i];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += __shfl_xor(acc[r], off, 64);
         if (lane == 0) {
-            logits[row] = acc0;
-            float v = acc0 != acc0 ? -INFINITY : acc0;  // NaN -> -inf (sampling.rs:45-49)
-            if (v > bv || (v == bv && row < bi)) {
-                bv = v;
-                bi = row;
-            }
-            if (two) {
-                logits[row + 1] = acc1;
-                v = acc1 != acc1 ? -INFINITY : acc1;
-                if (v > bv || (v == bv && row + 1 < bi)) {
-                    bv = v;
-                    bi = row + 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (row + r < vocab) {
+                    logits[row + r] = acc[r];
+                    const float v = acc[r] != acc[r] ? -INFINITY : acc[r];  // NaN -> -inf (sampling.rs:45-49)
+                    if (v > bv || (v == bv && row + r < bi)) {
+                        bv = v;
+                        bi = row + r;
+                    }
                 }
-            }
         }
     }
     if (lane == 0) {
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(256) void k_logits_f16(const _Float16 *__restrict__
     }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (wbv[w] > bv || (wbv[w] == bv && wbi[w] < bi)) {
-                bv = wbv[w];
-                bi = wbi[w];
+        for (int w2 = 1; w2 < 4; ++w2)
+            if (wbv[w2] > bv || (wbv[w2] == bv && wbi[w2] < bi)) {
+                bv = wbv[w2];
+                bi = wbi[w2];
             }
         best_val[blockIdx.x] = bv;
         best_idx[blockIdx.x] = bi;
@@ -234,8 +235,18 @@ __global__ __launch_bounds__(256) void k_argmax_final(const float *__restrict__ 
 hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,
                              float *logits, float *best_val, int *best_idx, int n_wg, hipStream_t stream) {
     if (hidden % 512 != 0 || hidden > 512 * kLogitChunks) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_logits_f16, dim3(n_wg), dim3(256), (size_t)hidden * sizeof(float), stream,
-                       static_cast<const _Float16 *>(table), x, gamma, eps, hidden, vocab, logits, best_val, best_idx);
+    void (*kfn)(const _Float16 *, const float *, const float *, float, int, int, float *, float *, int *) = nullptr;
+    const int rows = getenv("BITNET_HIP_LOGIT_ROWS") ? atoi(getenv("BITNET_HIP_LOGIT_ROWS")) : 3;  // tuning knob
+    switch (hidden / 512) {
+        case 1: kfn = k_logits_f16<1, 4>; break;
+        case 2: kfn = k_logits_f16<2, 4>; break;
+        case 4: kfn = k_logits_f16<4, 4>; break;
+        case 5: kfn = rows == 2 ? k_logits_f16<5, 2> : rows == 3 ? k_logits_f16<5, 3> : k_logits_f16<5, 4>; break;  // 2560: bitnet-b1.58-2B-4T
+        case 8: kfn = k_logits_f16<8, 2>; break;
+        default: kfn = hidden / 512 <= 8 ? k_logits_f16<8, 2, true> : k_logits_f16<16, 1, true>; break;
+    }
+    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(256), (size_t)hidden * sizeof(float), stream, static_cast<const _Float16 *>(table), x, gamma,
+                       eps, hidden, vocab, logits, best_val, best_idx);
     return hipGetLastError();
 }
 

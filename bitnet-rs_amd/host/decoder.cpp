@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -38,6 +39,7 @@ static hipError_t dalloc(T **p, size_t n) {
 }
 
 Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
+    if (const char *e = getenv("BITNET_HOST_LOGITS_WGS")) logits_wgs_ = atoi(e) > 0 ? atoi(e) : logits_wgs_;  // tuning knob
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
         err_ = e ? e : "bitnet_hip_init failed";
