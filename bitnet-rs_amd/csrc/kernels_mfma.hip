@@ -77,6 +77,7 @@ struct MfmaArgs {
     int rows, cols, nblk;  // nblk = ceil(cols / 256)
     uint32_t lut;
     int ksplit;            // 1, 2, 4 or 8 K ranges per row tile (waves of one workgroup)
+    int ks_log2;           // log2(ksplit): the index math ahead of the first load uses shifts, not divisions
     const float *x;        // [mt, cols]
     float *y;              // [mt, rows]  (silu_mul: [mt, rows/2])
     const float *ln_gamma; // optional LayerNorm prologue (T:67-100 semantics)
@@ -182,12 +183,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     BH_STAMP(0);
 
     // ---- wave -> (row tile, K range of at most RING 256-column blocks) ------------------
-    const int tiles_per_wg = NW / p.ksplit;
+    const int tiles_per_wg = NW >> p.ks_log2;
     const int n_tiles = (p.rows + 15) >> 4;
-    int tile = blockIdx.x * tiles_per_wg + wave / p.ksplit;
+    int tile = blockIdx.x * tiles_per_wg + (wave >> p.ks_log2);
     tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
-    const int kpart = wave % p.ksplit;
-    const int b0 = (kpart * p.nblk) / p.ksplit, b1 = ((kpart + 1) * p.nblk) / p.ksplit;
+    const int kpart = wave & (p.ksplit - 1);
+    const int b0 = (kpart * p.nblk) >> p.ks_log2, b1 = ((kpart + 1) * p.nblk) >> p.ks_log2;
     const int nvec = p.cols >> 2;  // cols % 4 == 0
 
     // ---- 1. activations first (vmcnt retires in order; these come from L2) ---------------
@@ -247,6 +248,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         }
         if (BS32 == 2) s_h[j] = load_nt16(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
     }
+    // Every load of this wave is now requested.  Without the fence hipcc moves the activation
+    // arithmetic (and its s_waitcnt) up between the weight loads, so that half of the weight stream is
+    // only requested once the activations have arrived (~1 us later).
+    __builtin_amdgcn_sched_barrier(0);
     BH_STAMP(1);
 
     // ---- 3. prologue: [LayerNorm] -> fixed point -> this wave's digit planes --------------
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             const int row = 16 * (blockIdx.x * tiles_per_wg + tl) + r;
             if (row < p.rows) {
                 float v = 0.0f;
-                for (int kp = 0; kp < p.ksplit; ++kp) v += part[(tl * p.ksplit + kp) * 16 + r];
+                for (int kp = 0; kp < p.ksplit; ++kp) v += part[((tl << p.ks_log2) + kp) * 16 + r];
                 if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) / ln_denom);
                 if (p.residual) v += p.residual[row];
                 p.y[row] = v;
@@ -471,8 +476,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             if (row < half_rows) {
                 float gv = 0.0f, uv = 0.0f;
                 for (int kp = 0; kp < p.ksplit; ++kp) {
-                    gv += part[((2 * pl) * p.ksplit + kp) * 16 + r];
-                    uv += part[((2 * pl + 1) * p.ksplit + kp) * 16 + r];
+                    gv += part[(((2 * pl) << p.ks_log2) + kp) * 16 + r];
+                    uv += part[(((2 * pl + 1) << p.ks_log2) + kp) * 16 + r];
                 }
                 if (LN == 2) {  // stored rows: (gate tile, up tile) pairs
                     const int t0 = blockIdx.x * tiles_per_wg + 2 * pl;
@@ -529,6 +534,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     // queue behind the first one's weight stream in the CU's memory pipeline
     const int nw = (getenv("BITNET_HIP_NW16") && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
+    a.ks_log2 = a.ksplit == 8 ? 3 : a.ksplit == 4 ? 2 : a.ksplit == 2 ? 1 : 0;
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
     a.ln_g = (fu.ln_gamma && w.ln_g && w.ln_gamma_bound == fu.ln_gamma) ? w.ln_g : nullptr;

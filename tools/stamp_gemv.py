@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--warm-ms", type=float, default=0)
     ap.add_argument("--replays", type=int, default=3)
     ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--fmt", default="qk256", choices=["qk256", "i2s32"], help="i2s32: ternary codes + f16-exact 32-block scales (BASELINE configs[1])")
     args = ap.parse_args()
     hip = pkg.HipLib(pkg.LIB_PATH.replace(".so", "_diag.so"))
     hip.init(0)
@@ -38,6 +39,9 @@ def main():
     stride = cols // 256 * 64
     rng = np.random.default_rng(0)
     def mk():
+        if args.fmt == "i2s32":
+            sc = (2.0 / ((np.arange(rows * (cols // 32)) % 100) + 1)).astype(np.float16).astype(np.float32)
+            return hip.weights_upload_i2s(rng.integers(0, 256, rows * cols // 4, dtype=np.uint8), sc, rows, cols, 32)
         return hip.weights_upload_qk256(rng.integers(0, 256, rows * stride, dtype=np.uint8), rows, cols, stride)
 
     if args.fused:  # the decode step's LayerNorm -> gate|up -> silu*mul launch
