@@ -68,6 +68,16 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
     float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos);  // [chunk][D][64]
     float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos);  // [max_pos][D]
+    // ---- the few loads RoPE needs go first (vmcnt retires in order: behind the 64 cache loads they
+    //      would only count as arrived once the whole K/V chunk has) ------------------------------------
+    //      All unconditional (clamped indices): a load under a branch makes hipcc wait at the join.
+    const int rg = tid >> 6, rj = tid & 63;  // RoPE on q: 4 heads x 64 rotation pairs = 256 threads
+    const float *q_raw = qkv + (size_t)(kvh * group + (rg < group ? rg : group - 1)) * kD;
+    const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
+    const float rs = sr[rj], rc = cr[rj], rq0 = q_raw[rj], rq1 = q_raw[half + rj];       // q: pair rj of head rg
+    const float rk0 = k_raw[rj], rk1 = k_raw[half + rj];                                  // new key: pair rj (threads < 64 use it)
+    const float rv = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid & 127)];  // new value: dim tid & 127
+    __builtin_amdgcn_sched_barrier(0);  // these seven requests first, then the cache stream
     // ---- every cache load of this thread is issued up front (none depends on q): the K
     //      slice for the score pass (lane = position) and the V column for the P.V pass
     //      (lane = dim); clamped addresses, masked later, so the loads are unconditional ----
@@ -85,32 +95,32 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             vv[i] = __builtin_nontemporal_load(vc + (size_t)jcl * kD + d);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep hipcc from moving the RoPE arithmetic (and its wait) up between the loads
     // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------
     {
-        const int g = tid >> 6, j = tid & 63;  // 4 heads x 64 rotation pairs = 256 threads
         float a = 0.0f, b = 0.0f;
-        if (g < group) {
-            const float *q_raw = qkv + (size_t)(kvh * group + g) * kD;
-            const float s = sr[j], c = cr[j], q0 = q_raw[j], q1 = q_raw[half + j];
-            a = q0 * c - q1 * s;
-            b = q0 * s + q1 * c;
+        if (rg < group) {
+            a = rq0 * rc - rq1 * rs;
+            b = rq0 * rs + rq1 * rc;
         }
-        qs[g * kD + j] = a;
-        qs[g * kD + half + j] = b;
+        qs[rg * kD + rj] = a;
+        qs[rg * kD + half + rj] = b;
     }
-    if (owns_new) {
-        if (tid < half) {
-            const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
-            const float s = sr[tid], c = cr[tid], k0 = k_raw[tid], k1 = k_raw[half + tid];
-            const float a = k0 * c - k1 * s, b = k0 * s + k1 * c;
-            kn[tid] = a;
-            kn[half + tid] = b;
-            kt[kidx(tid, pos)] = a;  // append (transposed)
-            kt[kidx(half + tid, pos)] = b;
-        } else if (tid >= 128) {
-            const float v = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid - 128)];
-            vn[tid - 128] = v;
-            vc[(size_t)pos * kD + (tid - 128)] = v;
+    // the new key / value go to LDS from EVERY thread of every workgroup (the four waves write the same
+    // values): used only under a branch, hipcc sinks their loads behind the cache stream, where the
+    // in-order counter makes them as late as the last cache byte.  Only the owning chunk appends to the cache.
+    {
+        const float a = rk0 * rc - rk1 * rs, b = rk0 * rs + rk1 * rc;  // rotation pair rj of the new key
+        kn[rj] = a;
+        kn[half + rj] = b;
+        vn[tid & 127] = rv;
+        if (owns_new) {
+            if (tid < half) {
+                kt[kidx(tid, pos)] = a;  // append (transposed)
+                kt[kidx(half + tid, pos)] = b;
+            } else if (tid >= 128) {
+                vc[(size_t)pos * kD + (tid - 128)] = rv;
+            }
         }
     }
     __syncthreads();
