@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float qs[kMaxGroup * kD];
     __shared__ float kn[kD], vn[kD];
     __shared__ float partial[4][kAttnChunk][kMaxGroup];
-    __shared__ float sc[kMaxGroup][kAttnChunk];
+    // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
+    // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
+    __shared__ __attribute__((aligned(16))) float sc[kMaxGroup][2][kAttnChunk / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = n_heads / n_kv, half = kD / 2;
     const bool owns_new = pos >= j0 && pos < j0 + kAttnChunk;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         m_c = awave_max(s);
         const float e = j < t_k ? expf(s - m_c) : 0.0f;
         l_c = awave_sum(e);
-        sc[g][lane] = e;
+        sc[g][lane & 1][lane >> 1] = e;
     }
     __syncthreads();
     // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
@@ -165,11 +167,21 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         const int cnt = t_k - j0 < kAttnChunk ? t_k - j0 : kAttnChunk;
         float a[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < kAttnChunk / 2; ++i) {
-            const int jj = 2 * i + hp;
-            const float v = jj < cnt ? (j0 + jj == pos ? vn[d] : vv[i]) : 0.0f;
+        for (int i = 0; i < kAttnChunk / 2; i += 4) {
+            float v4[4];
 #pragma unroll
-            for (int g = 0; g < kMaxGroup; ++g) a[g] += sc[g][jj] * v;
+            for (int u = 0; u < 4; ++u) {
+                const int jj = 2 * (i + u) + hp;
+                v4[u] = jj < cnt ? (j0 + jj == pos ? vn[d] : vv[i + u]) : 0.0f;
+            }
+#pragma unroll
+            for (int g = 0; g < kMaxGroup; ++g) {
+                const float4 w = *reinterpret_cast<const float4 *>(&sc[g][hp][i]);
+                a[g] += w.x * v4[0];
+                a[g] += w.y * v4[1];
+                a[g] += w.z * v4[2];
+                a[g] += w.w * v4[3];
+            }
         }
         // the two position parities meet through LDS (reuse the score partials buffer)
         float *red = &partial[0][0][0];  // [2][kMaxGroup][kD] = 1024 floats = sizeof(partial)
