@@ -98,17 +98,26 @@ def cpu_baseline(cfg, synth):
     one_layer()
     t_layer = float(np.median([one_layer() for _ in range(5)]))
     # (ii) the same kernel with the rows partitioned over all host cores ("reference kernel, parallelised")
-    n_cores = os.cpu_count() or 1
-    t_layer_mt = None
+    # host threads this process may use, capped: one thread per core pays off up to a few dozen rows-partitions
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cores = os.cpu_count() or 1
+    n_cores = max(1, min(n_cores, 32))
+    t_layer_mt, n_used = None, 1
     if orc.have_avx2() and n_cores > 1:
-        def one_layer_mt():
-            t0 = time.perf_counter()
-            for name, (rows, cols) in shapes.items():
-                orc.gemv_qk256(w[name], xs[cols], rows, cols, cols // 256 * 64, impl="avx2_mt", threads=n_cores)
-            return time.perf_counter() - t0
+        # the restated kernel spawns its row-partition threads per call: take the best of a few thread counts
+        for nt in sorted({t for t in (4, 8, 16, 32) if t <= n_cores} | {min(n_cores, 32)}):
+            def one_layer_mt():
+                t0 = time.perf_counter()
+                for name, (rows, cols) in shapes.items():
+                    orc.gemv_qk256(w[name], xs[cols], rows, cols, cols // 256 * 64, impl="avx2_mt", threads=nt)
+                return time.perf_counter() - t0
 
-        one_layer_mt()
-        t_layer_mt = float(np.median([one_layer_mt() for _ in range(5)]))
+            one_layer_mt()
+            t = float(np.median([one_layer_mt() for _ in range(5)]))
+            if t_layer_mt is None or t < t_layer_mt:
+                t_layer_mt, n_used = t, nt
     # logits: f32 accumulate over the f16 table, one thread; timed on 1/16 of the rows
     rows = cfg.vocab // 16
     table = np.random.default_rng(7).standard_normal((rows, cfg.hidden)).astype(np.float16).astype(np.float32)
@@ -119,7 +128,7 @@ def cpu_baseline(cfg, synth):
     tok_s = 1.0 / (cfg.n_layers * t_layer + t_logits)
     extra = {}
     if t_layer_mt is not None:
-        extra = {"all_cores": {"value": round(1.0 / (cfg.n_layers * t_layer_mt + t_logits / n_cores), 4), "unit": "tokens/s", "cores": n_cores,
+        extra = {"all_cores": {"value": round(1.0 / (cfg.n_layers * t_layer_mt + t_logits / n_used), 4), "unit": "tokens/s", "cores": n_used,
                                "note": "same AVX2 kernel, rows partitioned over all host threads (the reference itself is single-threaded here); logits scaled by 1/cores"}}
     return {
         "value": round(tok_s, 4),

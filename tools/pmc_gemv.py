@@ -48,6 +48,9 @@ def main():
             "g1": torch.from_numpy(w["attn_norm"]).cuda(),
             "g2": torch.from_numpy(w["ffn_norm"]).cuda(),
         }
+        # the decoder binds the LayerNorm weights (LayerNorm applied after the product): same kernel variant here
+        hip.weights_bind_ln(fused["qkv"], fused["g1"])
+        hip.weights_bind_ln(fused["gateup"], fused["g2"])
         for n in ("q", "k", "v", "gate", "up"):
             hip.weights_free(h[n])
         layers.append(fused)
