@@ -29,6 +29,7 @@ def init(backend: str | None = None) -> Rank:
     import torch
     import torch.distributed as dist
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL peer buffers)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
