@@ -130,3 +130,30 @@ def test_ternary_scaled_gemm(hip, oracle, torch_, block):
         got = run_gemm(hip, torch_, h, x, n, digits)
         assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)) + 1e-6, (block, digits)
     hip.weights_free(h)
+
+
+def test_full_size_gemm_properties(hip, torch_):
+    """BASELINE shapes (gate|up 13824 x 2560, 1024 rows): properties that need no oracle.
+    * row independence: a row's result does not depend on the other rows of the batch;
+    * exact power-of-two scaling: scaling a row by 2^k scales its fixed-point image exactly;
+    * zero rows give exact zeros; the 3-digit result stays within 2^-20 of the 4-digit one (relative to the row's scale)."""
+    rng = np.random.default_rng(123)
+    n, k, m = 13824, 2560, 1024
+    stride = k // 256 * 64
+    h = hip.weights_upload_qk256(rng.integers(0, 256, n * stride, dtype=np.uint8), n, k, stride)
+    x = rng.normal(0, 1, (m, k)).astype(np.float32)
+    x[7] = 0.0
+    y4 = run_gemm(hip, torch_, h, x, n, 4)
+    assert not np.isnan(y4).any() and not y4[7].any()
+    perm = rng.permutation(m)
+    yp = run_gemm(hip, torch_, h, x[perm], n, 4)
+    assert np.array_equal(yp, y4[perm])                                   # rows are independent, bit for bit
+    xs = x.copy()
+    xs[::2] *= 8.0
+    xs[1::2] *= 0.25
+    ys = run_gemm(hip, torch_, h, xs, n, 4)
+    assert np.array_equal(ys[::2], y4[::2] * 8.0) and np.array_equal(ys[1::2], y4[1::2] * 0.25)
+    y3 = run_gemm(hip, torch_, h, x, n, 3)
+    bound = np.abs(x).max(axis=1, keepdims=True) * 2.0 ** -21 * 2 * k     # <= 2^-22 of the row maximum per element, |w| <= 2
+    assert np.all(np.abs(y3 - y4) <= bound + 1e-6)
+    hip.weights_free(h)

@@ -220,3 +220,49 @@ def test_qk256_gemv_batch_dropin(hip, oracle):
         assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)) + 1e-6
     with pytest.raises(Exception, match="multiple of 256"):
         hip.qk256_gemv_batch([(np.zeros(64, np.uint8), np.ones(1, np.float32), np.zeros(100, np.float32), 1, 1, 100)])
+
+
+def test_prefill_attention_is_causal_and_block_independent(hip, oracle, torch_):
+    """Properties at a long sequence (2,000 tokens, 2B-4T head counts): outputs of positions < t do not
+    change when tokens >= t change (bit for bit), and a token-parallel call that only holds the first
+    1,024 queries (64-row blocks in any order) reproduces those rows exactly."""
+    n_heads, n_kv, D, T, max_pos = 20, 5, 128, 2000, 2048
+    rng = np.random.default_rng(2000)
+    qkv = rng.normal(0, 1.2, (T, (n_heads + 2 * n_kv) * D)).astype(np.float32)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    sin_d, cos_d = dev(sin), dev(cos)
+    wsb = hip.attention_prefill_workspace_bytes(n_heads, n_kv, T)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+
+    def run(x):
+        kc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+        vc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+        out = torch_.empty(T, n_heads * D, device="cuda")
+        hip.attention_prefill_dev(dev(x), sin_d, cos_d, kc, vc, n_heads, n_kv, D, max_pos, T, ws, wsb, out)
+        torch_.cuda.synchronize()
+        return out.cpu().numpy()
+
+    base = run(qkv)
+    t = 1217
+    changed = qkv.copy()
+    changed[t:] = rng.normal(0, 3.0, changed[t:].shape).astype(np.float32)
+    got = run(changed)
+    assert np.array_equal(got[:t], base[:t])
+    assert not np.array_equal(got[t:], base[t:])
+    # sharded call: queries 0..1023 as 16 blocks in a shuffled order, full context
+    nq = 1024
+    order = rng.permutation(nq // 64)
+    rows = np.concatenate([np.arange(64 * b, 64 * b + 64) for b in order])
+    kv_all = dev(qkv[:, n_heads * D:])
+    q_local = dev(qkv[rows][:, : n_heads * D])
+    bp = torch_.from_numpy((order * 64).astype(np.int32)).cuda()
+    wsb2 = hip.attention_prefill_sharded_workspace_bytes(n_heads, n_kv, nq, T)
+    ws2 = torch_.empty(wsb2, dtype=torch_.uint8, device="cuda")
+    kc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    vc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    out = torch_.empty(nq, n_heads * D, device="cuda")
+    hip.attention_prefill_sharded_dev(q_local, n_heads * D, bp, nq, kv_all, 2 * n_kv * D, T, sin_d, cos_d, kc, vc, n_heads, n_kv, D, max_pos, ws2,
+                                      wsb2, out)
+    torch_.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), base[rows])
