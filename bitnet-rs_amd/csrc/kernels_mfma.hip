@@ -79,7 +79,8 @@ struct MfmaArgs {
     int ksplit;            // 1, 2, 4 or 8 K ranges per row tile (waves of one workgroup)
     int ks_log2;           // log2(ksplit): the index math ahead of the first load uses shifts, not divisions
     const float *x;        // [mt, cols]
-    float *y;              // [mt, rows]  (silu_mul: [mt, rows/2])
+    float *y;              // [mt, rows]  (silu_mul: [mt, rows/2]); activation row blockIdx.y
+    int out_rows;          // row stride of y
     const float *ln_gamma; // optional LayerNorm prologue (T:67-100 semantics)
     const float *ln_g;     // LN == 2: g_r = W[r,:] . gamma  (bitnet_hip_weights_bind_ln)
     float ln_eps;
@@ -175,6 +176,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
+    // several activation rows (prompt rows of a format the tiled matmul does not take): grid.y walks them
+    const float *px = p.x + (size_t)blockIdx.y * p.cols;
+    float *py = p.y + (size_t)blockIdx.y * p.out_rows;
+    const float *pres = p.residual ? p.residual + (size_t)blockIdx.y * p.rows : nullptr;
     constexpr int ps = RING * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
     uint8_t *planes = lds + wave * 4 * ps;                          // this wave's [4][ps]
     double *stat = reinterpret_cast<double *>(lds + NW * 4 * ps);   // [NW][2] LayerNorm sums
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + NT * i;
             const int ci = idx < nvec ? idx : nvec - 1;
-            sx[i] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+            sx[i] = *reinterpret_cast<const float4 *>(px + 4 * ci);
             sg[i] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
         }
     } else if (LN == 2) {
@@ -211,20 +216,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         for (int j = 0; j < RING; ++j) {
             const int idx = (b0 + j) * 64 + lane;
             const int ci = idx < nvec ? idx : nvec - 1;
-            xr[j] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+            xr[j] = *reinterpret_cast<const float4 *>(px + 4 * ci);
             gr[j] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + NT * i;
-            sx[i] = *reinterpret_cast<const float4 *>(p.x + 4 * (idx < nvec ? idx : nvec - 1));
+            sx[i] = *reinterpret_cast<const float4 *>(px + 4 * (idx < nvec ? idx : nvec - 1));
         }
     } else {
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             const int idx = (b0 + j) * 64 + lane;
             const int ci = idx < nvec ? idx : nvec - 1;
-            xr[j] = *reinterpret_cast<const float4 *>(p.x + 4 * ci);
+            xr[j] = *reinterpret_cast<const float4 *>(px + 4 * ci);
         }
     }
 
@@ -462,8 +467,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 float v = 0.0f;
                 for (int kp = 0; kp < p.ksplit; ++kp) v += part[((tl << p.ks_log2) + kp) * 16 + r];
                 if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) / ln_denom);
-                if (p.residual) v += p.residual[row];
-                p.y[row] = v;
+                if (pres) v += pres[row];
+                py[row] = v;
             }
         }
     } else {
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                     gv = (float)(((double)gv - ln_mean * (double)p.ln_g[16 * t0 + r]) / ln_denom);
                     uv = (float)(((double)uv - ln_mean * (double)p.ln_g[16 * (t0 + 1) + r]) / ln_denom);
                 }
-                p.y[row] = gv / (1.0f + expf(-gv)) * uv;
+                py[row] = gv / (1.0f + expf(-gv)) * uv;
             }
         }
     }
@@ -575,11 +580,14 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
             raised.insert((const void *)kfn);
         }
     }
-    for (size_t m0 = 0; m0 < m; ++m0) {  // one activation row per launch (forward_qk256's row loop, T:683-691)
+    // one activation row per workgroup row of the grid (forward_qk256's row loop, T:683-691, in one launch)
+    a.out_rows = (int)out_rows;
+    for (size_t m0 = 0; m0 < m; m0 += 65535) {
+        const size_t mc = m - m0 < 65535 ? m - m0 : 65535;
         a.x = x + m0 * w.cols;
         a.y = y + m0 * out_rows;
         a.residual = fu.residual ? fu.residual + m0 * w.rows : nullptr;
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, stream, a);
+        hipLaunchKernelGGL(kfn, dim3(grid, (unsigned)mc), dim3(nw * 64), lds, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
