@@ -175,7 +175,10 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
     return ((float)acc[0][j] + 256.0f * (float)acc[1][j]) + (65536.0f * (float)acc[2][j] + 16777216.0f * (float)acc[3][j]);
 }
 
-template <int NDIG, int TTW, bool WS>
+// WS: 0 no weight scales; 1 one f32 scale per (row, 256-block); 2 one per (row, 32-block): the four
+// lane groups of an MFMA's K = 64 belong to four different 32-blocks, so B is masked to one lane group at a
+// time (4x the MFMAs) and every pair of MFMAs is folded into f32 with its block's scale.
+template <int NDIG, int TTW, int WS>
 __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
     constexpr int WG_COLS = 2 * CT * 16;    // plane rows per workgroup
@@ -245,6 +248,21 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
                 for (int j = 0; j < 4; ++j) facc[rt][tt][j] = 0.0f;
     }
     const uint8_t *bread = lds + (cw * CT * 16 + c) * kColStride + 64 * g;
+    // 32-block scales: element offset of (this lane's output row, block 0) in the [rows, cols / 32] scale array
+    int soff[WS == 2 ? 4 : 1][4];
+    if (WS == 2) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            int t = bx * 16 + rw * 4 + rt;
+            t = t < n_tiles ? t : n_tiles - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = 16 * t + 4 * g + j;
+                row = row < p.rows ? row : p.rows - 1;
+                soff[rt][j] = row * (p.nblk * 8);
+            }
+        }
+    }
 
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = bread;
@@ -277,23 +295,63 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n2 * 256);
         }
+        if (WS != 2) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v4i a[4];
+            for (int m = 0; m < 4; ++m) {
+                v4i a[4];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
-                a[rt] = gdecode16(wd, p.lut);
+                for (int rt = 0; rt < 4; ++rt) {
+                    const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
+                    a[rt] = gdecode16(wd, p.lut);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const v4i b = *reinterpret_cast<const v4i *>(bcur + ct * 16 * kColStride + 16 * m);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
+                }
             }
+        } else {
+            // k-slot (lane group kg, dword m, byte j) = column 64 kg + 16 m + j of the block: 32-block 2 kg + (m >> 1)
+#pragma unroll 1
+            for (int kg = 0; kg < 4; ++kg) {
+                const int live = g == kg ? -1 : 0;
+#pragma unroll 1
+                for (int mp = 0; mp < 2; ++mp) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const v4i b = *reinterpret_cast<const v4i *>(bcur + ct * 16 * kColStride + 16 * m);
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int m = 2 * mp + mm;
+                        v4i a[4];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
+                        for (int rt = 0; rt < 4; ++rt) {
+                            const uint32_t lo = mm == 0 ? wc[rt].x : wc[rt].y, hi = mm == 0 ? wc[rt].z : wc[rt].w;
+                            a[rt] = gdecode16(mp == 0 ? lo : hi, p.lut);  // dword m = 2 mp + mm
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            v4i b = *reinterpret_cast<const v4i *>(bcur + ct * 16 * kColStride + 16 * m);
+                            b[0] &= live, b[1] &= live, b[2] &= live, b[3] &= live;
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
+                        }
+                    }
+                    const int sb = 8 * blk + 2 * kg + mp;  // this pair's 32-block
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float sv = p.wscale[soff[rt][j] + sb];
+#pragma unroll
+                            for (int tt = 0; tt < TTW; ++tt) facc[rt][tt][j] += combine_digits<NDIG>(&acc[rt][tt * NDIG], j) * sv;
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4i){0, 0, 0, 0};
+                    }
+                }
             }
         }
         if (!WS) __syncthreads();  // every wave is done with buffer blk & 1
-        if (WS) {
+        if (WS == 1) {
             // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
@@ -360,12 +418,12 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int gemm_ttw(int ndig, bool ws) { return (ndig == 2 && !ws) ? 4 : 2; }
+static int gemm_ttw(int ndig, int ws) { return ws == 2 ? 1 : (ndig == 2 && !ws) ? 4 : 2; }
 
 bool gemm_supported(const Weights &w) {
     if (!w.tiles || w.cols % 4 != 0 || w.cols > 8192) return false;
     if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;
-    if (w.scales && w.block_size != 256) return false;  // 32-element block scales: GEMV path only
+    if (w.scales && w.block_size != 256 && !(w.block_size == 32 && w.cols % 256 == 0)) return false;
     return true;
 }
 
@@ -381,8 +439,9 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<NDIG, 3> : k_quant_rows<NDIG, 8>;
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
-    void (*gk)(GemmArgs) = a.wscale ? k_gemm_mfma<NDIG, TTWS, true> : k_gemm_mfma<NDIG, TTW, false>;
-    const int ttw = a.wscale ? TTWS : TTW;
+    const bool bs32 = a.wscale && w.block_size == 32;  // 32-block scales: one token tile per wave (registers)
+    void (*gk)(GemmArgs) = !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, 1, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
+    const int ttw = !a.wscale ? TTW : bs32 ? 1 : TTWS;
     const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (a.wscale ? 1 : 2);  // unscaled variant: double-buffered
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
@@ -399,7 +458,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
                             void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
     if (workspace_bytes < gemm_workspace_bytes(m, w.cols, ndig) || !workspace) return hipErrorInvalidValue;
-    const bool ws_mode = w.scales && w.block_size == 256;
+    const int ws_mode = !w.scales ? 0 : w.block_size == 32 ? 2 : 1;
     const size_t wg_tokens = (size_t)32 * gemm_ttw(ndig, ws_mode), m_pad = div_ceil(m, wg_tokens) * wg_tokens;
     QuantArgs q;
     q.x = x;
@@ -424,7 +483,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.y = y;
     a.m = (int)m;
     a.residual = fu.residual;
-    a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
+    a.wscale = w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
