@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int gemm_ttw(int ndig, int ws) { return ws == 2 ? 1 : (ndig == 2 && !ws) ? 4 : 2; }
+static int gemm_ttw(int ndig, int ws) { return ws == 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 bool gemm_supported(const Weights &w) {
     if (!w.tiles || w.cols % 4 != 0 || w.cols > 8192) return false;
@@ -440,8 +440,9 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
     const bool bs32 = a.wscale && w.block_size == 32;  // 32-block scales: one token tile per wave (registers)
-    void (*gk)(GemmArgs) = !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, 1, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    const int ttw = !a.wscale ? TTW : bs32 ? 1 : TTWS;
+    constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
+    void (*gk)(GemmArgs) = !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
+    const int ttw = !a.wscale ? TTW : bs32 ? TT32 : TTWS;
     const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (a.wscale ? 1 : 2);  // unscaled variant: double-buffered
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
