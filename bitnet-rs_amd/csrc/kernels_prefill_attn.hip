@@ -9,7 +9,7 @@
 //                   and the f32 decode cache (transposed, [kv][128][max_pos]); v -> f16
 //                   transposed [kv][128][T] and the f32 decode cache [kv][max_pos][128].
 //                   Every global access is contiguous along the fastest index.
-//   k_prefill_attn  grid (T/64, heads), 4 waves x 16 queries: flash attention on
+//   k_prefill_attn  8 waves = (heads of one KV head) x (groups of 16 queries): flash attention on
 //                   v_mfma_f32_16x16x32_f16, f32 accumulation and f32 online softmax.
 //                   It works on S^T = K Q^T and O^T = V^T P^T so that the probabilities never
 //                   leave registers: an S^T accumulator (lane: query c, keys 4g..4g+3) is
@@ -26,7 +26,8 @@ typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kPD = 128;       // head dim
-constexpr int kQB = 64;        // queries / keys per block
+constexpr int kQB = 64;        // keys per tile; query rows come in 64-row blocks (q_block_pos)
+constexpr int kQPad = 128;     // query rows are padded to this (the largest workgroup query tile)
 constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
 constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
 
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     const float *src = is_q ? p.q + (size_t)slot * p.hs_q
                      : is_k ? p.k + (size_t)(slot - p.n_heads) * p.hs_kv : p.v + (size_t)(slot - p.n_heads - p.n_kv) * p.hs_kv;
     const int ld = is_q ? p.ld_q : p.ld_kv;
-    const int pos0 = is_q && p.q_block_pos ? p.q_block_pos[blockIdx.x] : t0;  // absolute position of row t0
+    // absolute position of row t0 (padding blocks past the last real one hold zeros: any position will do)
+    const int pos0 = is_q && p.q_block_pos ? ((int)blockIdx.x < (p.nq + kQB - 1) / kQB ? p.q_block_pos[blockIdx.x] : 0) : t0;
     for (int i = 0; i < 32; ++i) {
         const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
         tile[tok][d] = t0 + tok < n_rows ? src[(size_t)(t0 + tok) * ld + d] : 0.0f;
@@ -111,17 +113,31 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
+// 8 waves per workgroup = HW query heads of ONE KV head x (8 / HW) groups of 16 queries: all of them multiply the
+// same K / V^T tiles, so a tile is staged into LDS once for 128 (query, head) pairs (GQA with 4 heads per KV head:
+// 4 heads x 32 queries) -- the kernel is bound by the tile traffic L2 -> CU, not by the matrix cores.
+template <int HW>
+__global__ __launch_bounds__(512) void k_prefill_attn(PrefillArgs p) {
+    constexpr int QW = 8 / HW, QG = 16 * QW;  // query groups of 16 per workgroup, queries per workgroup
     __shared__ __attribute__((aligned(16))) uint8_t ks[kQB * kKPitch];
     __shared__ __attribute__((aligned(16))) uint8_t vs[kPD * kVPitch];
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
-    const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv);
+    __shared__ int s_last;
+    const int qg = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int qrow = qb * kQB + wave * 16 + c;                    // this lane's query row (B-operand column)
-    const int bpos = p.q_block_pos ? p.q_block_pos[qb] : qb * kQB;  // absolute position of the block's first query
-    const int qpos = bpos + wave * 16 + c;
-    // last key tile any query of the block sees
-    const int kt_last = p.causal ? (bpos + kQB - 1 < p.T ? bpos + kQB - 1 : p.T - 1) / kQB : (p.T - 1) / kQB;
+    const int h = blockIdx.y * HW + wave % HW, kvh = h / (p.n_heads / p.n_kv);  // HW divides the group: one KV head per workgroup
+    const int qbase = qg * QG + (wave / HW) * 16;                 // first query row of this wave
+    const int qrow = qbase + c;                                   // this lane's query row (B-operand column)
+    const int blk64 = qbase >> 6;                                 // the 64-row block the wave's rows lie in
+    const int bpos = (p.q_block_pos ? p.q_block_pos[blk64 < (p.nq + kQB - 1) / kQB ? blk64 : 0] : blk64 * kQB) + (qbase & 63);
+    const int qpos = bpos + c;
+    if (tid == 0) s_last = 0;
+    __syncthreads();
+    {   // last key tile any query of the workgroup sees
+        const int need = p.causal ? (bpos + 15 < p.T ? bpos + 15 : p.T - 1) / kQB : (p.T - 1) / kQB;
+        if (lane == 0) atomicMax(&s_last, need);
+    }
+    __syncthreads();
+    const int kt_last = s_last;
     const int qlim = p.causal ? qpos : p.T - 1;  // highest visible key position
     // Q^T operand: 8 consecutive dims per k-slot group, kept in registers for the whole block
     v8h qreg[4];
@@ -141,8 +157,8 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     for (int kt = 0; kt <= kt_last; ++kt) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i;
             {   // K tile: 64 keys x 128 dims, contiguous 16 KB
                 const int pos = idx >> 4, seg = idx & 15;
                 *reinterpret_cast<uint4 *>(ks + pos * kKPitch + seg * 16) =
@@ -225,8 +241,18 @@ __global__ __launch_bounds__(256) void k_prefill_attn(PrefillArgs p) {
     }
 }
 
+static void launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
+    const int group = p.n_heads / p.n_kv;
+    if (group % 4 == 0)
+        hipLaunchKernelGGL(k_prefill_attn<4>, dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4)), dim3(512), 0, stream, p);
+    else if (group % 2 == 0)
+        hipLaunchKernelGGL(k_prefill_attn<2>, dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2)), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL(k_prefill_attn<1>, dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads), dim3(512), 0, stream, p);
+}
+
 size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
-    const size_t qpad = div_ceil((size_t)nq, kQB) * kQB, tpad = div_ceil((size_t)T, kQB) * kQB;
+    const size_t qpad = div_ceil((size_t)nq, kQPad) * kQPad, tpad = div_ceil((size_t)T, kQB) * kQB;
     return ((size_t)n_heads * qpad + 2 * (size_t)n_kv * tpad) * kPD * sizeof(_Float16) + 256;
 }
 
@@ -251,7 +277,7 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.scale = 1.0f / sqrtf((float)kPD);
     p.q_block_pos = q_block_pos;
     p.nq = nq;
-    p.nq_pad = (int)(div_ceil((size_t)nq, kQB) * kQB);
+    p.nq_pad = (int)(div_ceil((size_t)nq, kQPad) * kQPad);
     p.rope_sin = rope_sin;
     p.rope_cos = rope_cos;
     p.kcache = kcache;
@@ -268,7 +294,7 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.out = out;
     const unsigned nbq = (unsigned)(p.nq_pad / kQB), nbk = (unsigned)(p.Tpad / kQB);
     hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_prefill_attn, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
+    launch_attn_kernel(p, stream);
     return hipGetLastError();
 }
 
@@ -291,13 +317,13 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.scale = scale;
     p.q_block_pos = nullptr;
     p.nq = seq;
-    p.nq_pad = (int)(div_ceil((size_t)seq, kQB) * kQB);
+    p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;
     p.kcache = p.vcache = nullptr;
     p.n_heads = p.n_kv = n_heads;
     p.max_pos = seq;
     p.T = seq;
-    p.Tpad = p.nq_pad;
+    p.Tpad = (int)(div_ceil((size_t)seq, kQB) * kQB);
     uint8_t *ws = reinterpret_cast<uint8_t *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     p.qh = reinterpret_cast<_Float16 *>(ws);
     p.kh = p.qh + (size_t)n_heads * p.nq_pad * kPD;
@@ -305,7 +331,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.out = out;
     const unsigned nb = (unsigned)(p.nq_pad / kQB);
     hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(3 * n_heads)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(k_prefill_attn, dim3(nb, (unsigned)n_heads), dim3(256), 0, stream, p);
+    launch_attn_kernel(p, stream);
     return hipGetLastError();
 }
 
