@@ -54,6 +54,9 @@ def main():
     else:
         handles = [mk() for _ in range(args.layers)]
     gamma = torch.full((cols,), 0.0125, device="cuda")
+    if args.fused:  # as the decoder does: LayerNorm applied after the product
+        for h in handles:
+            hip.weights_bind_ln(h, gamma)
     hip.set_kernel({"mfma": pkg.KERNEL_MFMA, "mfma_tiled": pkg.KERNEL_MFMA_TILED}[args.kernel])
     x = torch.randn(cols, device="cuda")
     y = torch.empty(2 * rows, device="cuda")
