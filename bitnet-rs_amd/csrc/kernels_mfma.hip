@@ -142,20 +142,22 @@ __device__ __forceinline__ v4i decode16(uint32_t w, uint32_t lut) {
     return a;
 }
 
-// 30-bit fixed point -> four balanced base-256 digits, one byte lane each.
-__device__ __forceinline__ void push_digits(float v, float sc, int b, uint32_t &d0, uint32_t &d1,
-                                            uint32_t &d2, uint32_t &d3) {
-    int q = __float2int_rn(v * sc);
-    const int e0 = (int)(int8_t)q;
-    q = (q - e0) >> 8;
-    const int e1 = (int)(int8_t)q;
-    q = (q - e1) >> 8;
-    const int e2 = (int)(int8_t)q;
-    q = (q - e2) >> 8;
-    d0 |= (uint32_t)(e0 & 0xff) << (8 * b);
-    d1 |= (uint32_t)(e1 & 0xff) << (8 * b);
-    d2 |= (uint32_t)(e2 & 0xff) << (8 * b);
-    d3 |= (uint32_t)(q & 0xff) << (8 * b);
+// 30-bit fixed point -> four balanced base-256 digits d0..d3 in [-128, 127], q = sum d_i 256^i.
+// Adding 0x808080 turns the three low digits into the UNSIGNED bytes of the sum (d_i + 128, the carries are the
+// adder's own), the top byte is already d3; flipping the three added bits back gives the signed digits:
+//     bytes of (q + 0x00808080) ^ 0x00808080  =  d0, d1, d2, d3        (two instructions per element)
+__device__ __forceinline__ uint32_t digits4(float v, float sc) {
+    return ((uint32_t)__float2int_rn(v * sc) + 0x00808080u) ^ 0x00808080u;
+}
+// 4 x 4 byte transpose: element dwords e0..e3 (byte i = digit i) -> plane dwords d0..d3 (byte b = element b)
+__device__ __forceinline__ void digit_planes(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t &d0, uint32_t &d1,
+                                             uint32_t &d2, uint32_t &d3) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(e1, e0, 0x05010400u), hi01 = __builtin_amdgcn_perm(e1, e0, 0x07030602u);
+    const uint32_t lo23 = __builtin_amdgcn_perm(e3, e2, 0x05010400u), hi23 = __builtin_amdgcn_perm(e3, e2, 0x07030602u);
+    d0 = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+    d1 = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+    d2 = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    d3 = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
 // NW waves per workgroup, RING = 256-column blocks per wave (all in flight at once), NV =
@@ -334,11 +336,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     const float inv_s = __uint_as_float((uint32_t)(be - 29) << 23);
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        push_digits(xr[j].x, sc, 0, d0, d1, d2, d3);
-        push_digits(xr[j].y, sc, 1, d0, d1, d2, d3);
-        push_digits(xr[j].z, sc, 2, d0, d1, d2, d3);
-        push_digits(xr[j].w, sc, 3, d0, d1, d2, d3);
+        uint32_t d0, d1, d2, d3;
+        digit_planes(digits4(xr[j].x, sc), digits4(xr[j].y, sc), digits4(xr[j].z, sc), digits4(xr[j].w, sc), d0, d1, d2, d3);
         const int pos = 256 * j + 4 * lane;
         *reinterpret_cast<uint32_t *>(planes + 0 * ps + pos) = d0;
         *reinterpret_cast<uint32_t *>(planes + 1 * ps + pos) = d1;
