@@ -138,21 +138,18 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + 256 * i;
         if (idx >= kvec) continue;
-        uint32_t dg[NDIG];
-#pragma unroll
-        for (int d = 0; d < NDIG; ++d) dg[d] = 0;
-        const float e4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int q = __float2int_rn(e4[b] * sc);
-#pragma unroll
-            for (int d = 0; d < NDIG - 1; ++d) {
-                const int e = (int)(int8_t)q;
-                q = (q - e) >> 8;
-                dg[d] |= (uint32_t)(e & 0xff) << (8 * b);
-            }
-            dg[NDIG - 1] |= (uint32_t)(q & 0xff) << (8 * b);
-        }
+        // balanced digits: bytes of (q + B) ^ B with B = 0x80 in the NDIG-1 low bytes (kernels_mfma.hip digits4),
+        // then a 4 x 4 byte transpose to one dword per digit plane (byte b = element b)
+        constexpr uint32_t B = NDIG == 4 ? 0x00808080u : NDIG == 3 ? 0x00008080u : 0x00000080u;
+        const uint32_t e0 = ((uint32_t)__float2int_rn(v[i].x * sc) + B) ^ B, e1 = ((uint32_t)__float2int_rn(v[i].y * sc) + B) ^ B;
+        const uint32_t e2 = ((uint32_t)__float2int_rn(v[i].z * sc) + B) ^ B, e3 = ((uint32_t)__float2int_rn(v[i].w * sc) + B) ^ B;
+        const uint32_t lo01 = __builtin_amdgcn_perm(e1, e0, 0x05010400u), hi01 = __builtin_amdgcn_perm(e1, e0, 0x07030602u);
+        const uint32_t lo23 = __builtin_amdgcn_perm(e3, e2, 0x05010400u), hi23 = __builtin_amdgcn_perm(e3, e2, 0x07030602u);
+        uint32_t dg[4];
+        dg[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+        dg[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+        dg[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+        dg[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 #pragma unroll
         for (int d = 0; d < NDIG; ++d) *reinterpret_cast<uint32_t *>(base + (size_t)d * 16 * p.kp + 4 * idx) = dg[d];
     }
