@@ -183,11 +183,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     float *py = p.y + (size_t)blockIdx.y * p.out_rows;
     const float *pres = p.residual ? p.residual + (size_t)blockIdx.y * p.rows : nullptr;
     constexpr int ps = RING * 256 + 16;  // plane stride: +16 B makes the B reads conflict-free
-    uint8_t *planes = lds + wave * 4 * ps;                          // this wave's [4][ps]
-    double *stat = reinterpret_cast<double *>(lds + NW * 4 * ps);   // [NW][2] LayerNorm sums
+    constexpr int NP = BS32 ? 5 : 4;  // 32-block mode: a fifth, all-zero plane per wave (see the main loop)
+    uint8_t *planes = lds + wave * NP * ps;                          // this wave's [NP][ps]
+    double *stat = reinterpret_cast<double *>(lds + NW * NP * ps);   // [NW][2] LayerNorm sums
     float *part = reinterpret_cast<float *>(stat + 2 * NW);         // [NW][16]
     float *vbuf = part + NW * 16;                                   // [cols] normalised row (LN only)
     BH_STAMP(0);
+    if (BS32) {  // zero plane, written while the first loads are in flight
+#pragma unroll
+        for (int j = 0; j < RING; ++j) *reinterpret_cast<uint32_t *>(planes + 4 * ps + 256 * j + 4 * lane) = 0u;
+    }
 
     // ---- wave -> (row tile, K range of at most RING 256-column blocks) ------------------
     const int tiles_per_wg = NW >> p.ks_log2;
@@ -350,8 +355,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     //         wave's accesses in order, no barrier needed.  Slots past the wave's range hold
     //         zero digits (and a re-read tile), so they add exact zeros. ----------------------
     // B operand of lane (col c = r16, k-group g): 16 bytes of plane c & 3.
-    const uint8_t *bbase = planes + (r16 & 3) * ps + 64 * g;
-    const int bmask = (r16 >> 2) == g ? -1 : 0;  // 32-block mode: this lane's B is live for k-group c>>2 only
+    // 32-block mode: column c = 4*kg + d is live for k-group kg only; the other lanes read the zero plane, so the
+    // loop carries no masking instructions (the kernel is VALU-issue bound)
+    const uint8_t *bbase = planes + ((!BS32 || (r16 >> 2) == g) ? (r16 & 3) : 4) * ps + 64 * g;
     v4i acc = {0, 0, 0, 0};
     float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -364,11 +370,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const v4i a = decode16(wd[m], p.lut);
-                v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * j + 16 * m);
-                b[0] &= bmask;
-                b[1] &= bmask;
-                b[2] &= bmask;
-                b[3] &= bmask;
+                const v4i b = *reinterpret_cast<const v4i *>(bbase + 256 * j + 16 * m);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
                 if (m & 1) {
                     float4 sv;
@@ -569,7 +571,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
 #undef BH_PICK
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;  // the instantiated RING (LDS plane stride)
-    const size_t lds = (size_t)nw * 4 * (ring_t * 256 + 16) + 2 * nw * sizeof(double) + nw * 16 * sizeof(float) +
+    const size_t lds = (size_t)nw * (bs32 ? 5 : 4) * (ring_t * 256 + 16) + 2 * nw * sizeof(double) + nw * 16 * sizeof(float) +
                        ((ln && !ln2) ? w.cols * sizeof(float) : 0);
     if (lds > 64 * 1024) {
         static std::unordered_set<const void *> raised;  // raised once per kernel, outside any capture
