@@ -209,7 +209,7 @@ def main():
     synth = importlib.import_module("bitnet-rs_amd.synth")
     dist_ = importlib.import_module("bitnet-rs_amd.dist")
     r = dist_.init("nccl")  # RCCL; one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torchrun)
-    world, rank, local_rank = r.world, r.rank, r.local_rank
+    world, rank, local_rank = r.world, r.rank, r.local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     n_gpus = world
     if not os.path.exists(pkg.LIB_PATH) or not os.path.exists(pkg.HOST_LIB_PATH):

@@ -32,11 +32,15 @@ def init(backend: str | None = None) -> Rank:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL peer buffers)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    backend = os.environ.get("BITNET_DIST_BACKEND", backend)  # rehearsals: gloo on a box with fewer GPUs than ranks
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        local_rank %= max(1, torch.cuda.device_count())
+        dist.init_process_group(backend)
     else:
         dist.init_process_group(backend)
     return Rank(world, rank, local_rank, backend)
