@@ -70,6 +70,20 @@ struct DevBuf {
     }
 };
 
+// Sizes are computed as products of caller-supplied dimensions: refuse anything whose products could
+// wrap size_t or exceed the kernels' 32-bit row/column indices before multiplying.
+bool dims_sane(size_t a, size_t b, size_t c = 1) {
+    const size_t lim = size_t(1) << 31;
+    if (a >= lim || b >= lim || c >= lim) return false;
+    unsigned long long ab = 0, abc = 0;
+    if (__builtin_mul_overflow((unsigned long long)a, (unsigned long long)b, &ab)) return false;
+    if (__builtin_mul_overflow(ab, (unsigned long long)c, &abc)) return false;
+    return abc < (1ull << 44);
+}
+#define BH_CHECK_DIMS(...)                                                                               \
+    if (!dims_sane(__VA_ARGS__))                                                                         \
+    return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions too large for this library (%s)", #__VA_ARGS__)
+
 int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvFusion &fu, hipStream_t stream) {
     int kernel = g_kernel;
     if (kernel == BITNET_HIP_KERNEL_AUTO) kernel = BITNET_HIP_KERNEL_MFMA;
@@ -199,6 +213,7 @@ int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_qk256");
     if (rows == 0 || cols == 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2SQk256NoScale: rows and cols must be > 0");
+    BH_CHECK_DIMS(rows, cols);
     const size_t stride = div_ceil(cols, 256) * 64;
     if (row_stride_bytes != stride)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
@@ -250,6 +265,7 @@ static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float
     if (block_size == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "block_size must be > 0");
     if (n == 0 || k == 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: n=%zu, k=%zu", n, k);
+    BH_CHECK_DIMS(n, k);
     const size_t packed_k = div_ceil(k, 4), nblk = div_ceil(k, block_size);
     if (w_len < packed_k * n)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_packed too small: expected %zu, got %zu",
@@ -314,6 +330,7 @@ int bitnet_hip_weights_upload_inline_f16(const uint8_t *blocks, size_t len, size
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_upload_inline_f16");
     if (n == 0 || k == 0 || k % 32 != 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "inline f16 blocks need k %% 32 == 0 and n, k > 0: n=%zu, k=%zu", n, k);
+    BH_CHECK_DIMS(n, k);
     const size_t nb = n * (k / 32);
     if (len < nb * 10)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "blocks too small: expected %zu, got %zu", nb * 10, len);
@@ -541,6 +558,7 @@ int bitnet_hip_rmsnorm(const float *input, size_t in_len, const float *gamma, si
     BH_GUARD_BEGIN
     if (!input || !gamma || !output) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to rmsnorm");
     if (hidden_dim == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "hidden_dim must be > 0");
+    BH_CHECK_DIMS(num_rows, hidden_dim);
     if (in_len < num_rows * hidden_dim || out_len < num_rows * hidden_dim || gamma_len < hidden_dim)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "rmsnorm: buffer too small for %zu rows x %zu", num_rows, hidden_dim);
     if (num_rows == 0) return BITNET_HIP_OK;
@@ -656,6 +674,7 @@ int bitnet_hip_attention(const float *q, size_t q_len, const float *k, size_t k_
                          size_t out_len, size_t seq_len, size_t num_heads, size_t head_dim, int causal, float scale) {
     BH_GUARD_BEGIN
     if (!q || !k || !v || !output) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention");
+    BH_CHECK_DIMS(num_heads, head_dim, seq_len);
     if (num_heads == 0 || head_dim == 0 || seq_len == 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: num_heads=%zu, head_dim=%zu, seq_len=%zu", num_heads, head_dim, seq_len);
     if (head_dim != 128) return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention: head_dim %zu unsupported (128)", head_dim);
@@ -736,6 +755,8 @@ int bitnet_hip_gemv_qk256(const uint8_t *qs_data, size_t qs_len, const float *x,
     BH_GUARD_BEGIN
     if (!qs_data || !x || !y_out)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_qk256");
+    BH_CHECK_DIMS(rows, cols);
+    BH_CHECK_DIMS(rows, row_stride_bytes);
     // Q/i2s_qk256.rs:301-311, same order, same wording
     if (y_len != rows)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2S_QK256: y_out length %zu != rows %zu", y_len, rows);
@@ -779,6 +800,7 @@ int bitnet_hip_i2s_matmul_f32(const float *act, size_t act_len, const uint8_t *w
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to i2s_matmul_f32");
     // K/cpu/quantized_matmul.rs:204-256
     if (block_size == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "block_size must be > 0");
+    BH_CHECK_DIMS(m, n, k);
     if (m == 0 || n == 0 || k == 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=%zu, n=%zu, k=%zu", m, n, k);
     const size_t packed_k = div_ceil(k, 4), nblk = div_ceil(k, block_size);
@@ -824,6 +846,7 @@ int bitnet_hip_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_
                           size_t m, size_t n, size_t k) {
     BH_GUARD_BEGIN
     if (!a || !b || !c) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_i2s");
+    BH_CHECK_DIMS(m, n, k);
     // K/cpu/fallback.rs:49-63
     if (a_len != m * k)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix A dimension mismatch: expected %zu, got %zu", m * k, a_len);
@@ -878,6 +901,7 @@ int bitnet_hip_dequant_i2s(const uint8_t *bytes, size_t bytes_len, size_t rows, 
     BH_GUARD_BEGIN
     if (!bytes || !out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to dequant_i2s");
     if (rows == 0 || cols == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2_S: empty tensor dims");
+    BH_CHECK_DIMS(rows, cols);
     if (out_len < rows * cols)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "I2_S: output bounds exceeded: %zu > %zu", rows * cols, out_len);
     // M/quant/i2s.rs:205-214 (non-transposed tries 256 first, which the candidate

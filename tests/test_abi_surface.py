@@ -94,3 +94,24 @@ def test_fails_loudly_without_gpu(lib, pkg):
 def test_missing_library_raises(pkg, tmp_path):
     with pytest.raises(FileNotFoundError, match="no fallback"):
         pkg.HipLib(str(tmp_path / "nope.so"))
+
+
+def test_overflowing_dimensions_are_refused_before_any_multiplication(lib):
+    """rows*stride etc. would wrap size_t: the entry points say so instead of computing with them."""
+    import ctypes as C
+
+    lib = C.CDLL(lib.path)
+    lib.bitnet_hip_get_last_error.restype = C.c_char_p
+    buf = (C.c_uint8 * 64)()
+    fl = (C.c_float * 64)()
+    h = C.c_uint64(0)
+    big = C.c_size_t(1 << 62)
+    lib.bitnet_hip_weights_upload_qk256.argtypes = [C.c_void_p, C.c_size_t] + [C.c_size_t] * 3 + [C.c_void_p]
+    rc = lib.bitnet_hip_weights_upload_qk256(buf, 64, big, 256, 64, C.byref(h))
+    assert rc != 0 and b"too large" in lib.bitnet_hip_get_last_error()
+    lib.bitnet_hip_gemv_qk256.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.c_size_t] * 3
+    rc = lib.bitnet_hip_gemv_qk256(buf, 64, fl, 64, fl, 1 << 62, big, 4, 4)
+    assert rc != 0 and b"too large" in lib.bitnet_hip_get_last_error()
+    lib.bitnet_hip_matmul_i2s.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.c_size_t] * 3
+    rc = lib.bitnet_hip_matmul_i2s(buf, 0, buf, 0, fl, 0, 1 << 32, 1 << 32, 0)
+    assert rc != 0 and b"too large" in lib.bitnet_hip_get_last_error()
