@@ -266,6 +266,11 @@ def main():
         "bytes_per_launch": int(abytes),
         "us_per_launch": round(us, 3),
     }
+    # quote the fraction against the vendor figure AND a stream ceiling measured on this box
+    # (read-only non-temporal stream over 2 GiB, best of 10 passes; bitnet_hip_hbm_read_ceiling)
+    ceil_best, ceil_mean = hip.hbm_read_ceiling(2 << 30, 10)
+    roofline["measured_read_ceiling"] = round(ceil_best, 1)
+    roofline["frac_of_measured_ceiling"] = round(achieved / ceil_best, 4)
     kernel_table = {}
     for kind, name in enumerate(("qkv", "attention", "o_proj", "gate_up", "down", "logits")):
         k_us, k_bytes = dec.probe_kernel(kind, 20)

@@ -137,6 +137,7 @@ class HipLib:
         L.bitnet_hip_attention_scratch_bytes.restype = _sz
         L.bitnet_hip_logits_f16_dev.argtypes = [_vp, _vp, _vp, C.c_float, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_argmax_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _vp]
+        L.bitnet_hip_hbm_read_ceiling.argtypes = [_sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]
 
     # -- helpers ---------------------------------------------------------
     def last_error(self) -> str:
@@ -358,6 +359,12 @@ class HipLib:
 
     def argmax_dev(self, v, n: int, scratch, n_wg: int, token, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_argmax_dev(_ptr(v), n, _ptr(scratch), n_wg, _ptr(token), _vp(stream)))
+
+    def hbm_read_ceiling(self, nbytes: int = 2 << 30, iters: int = 10, stream: int = 0):
+        """Measured read-only stream ceiling of the device: (best, mean) GB/s."""
+        best, mean = C.c_double(0.0), C.c_double(0.0)
+        self._check(self.c.bitnet_hip_hbm_read_ceiling(nbytes, iters, C.byref(best), C.byref(mean), _vp(stream)))
+        return best.value, mean.value
 
 
 _lib = None

@@ -929,6 +929,46 @@ int bitnet_hip_dequant_i2s(const uint8_t *bytes, size_t bytes_len, size_t rows, 
     BH_GUARD_END
 }
 
+int bitnet_hip_hbm_read_ceiling(size_t bytes, int iters, double *best_gbs, double *mean_gbs, void *stream) {
+    BH_GUARD_BEGIN
+    if (!best_gbs || !mean_gbs) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to hbm_read_ceiling");
+    if (bytes < (size_t(1) << 20) || bytes > (size_t(64) << 30) || iters < 1 || iters > 1000)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "hbm_read_ceiling: bytes in [1 MiB, 64 GiB], iters in [1, 1000]");
+    int rc = ensure_init();
+    if (rc) return rc;
+    bytes &= ~size_t(15);
+    DevBuf buf, sink;
+    if (buf.alloc(bytes) != hipSuccess || sink.alloc(64) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc(%zu) failed in hbm_read_ceiling", bytes);
+    hipStream_t s = (hipStream_t)stream;
+    BH_HIP_TRY(hipMemsetAsync(buf.p, 0x5a, bytes, s));
+    hipEvent_t e0, e1;
+    BH_HIP_TRY(hipEventCreate(&e0));
+    BH_HIP_TRY(hipEventCreate(&e1));
+    double best = 0.0, sum = 0.0;
+    hipError_t e = launch_stream_read(buf.p, bytes, sink.as<unsigned>(), s);  // warm-up (code load)
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        e = hipEventRecord(e0, s);
+        if (e == hipSuccess) e = launch_stream_read(buf.p, bytes, sink.as<unsigned>(), s);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0.f) {
+            const double g = (double)bytes / (ms * 1e-3) / 1e9;
+            best = g > best ? g : best;
+            sum += g;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "hbm_read_ceiling failed: %s", hipGetErrorString(e));
+    *best_gbs = best;
+    *mean_gbs = sum / iters;
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 #ifdef BH_STAMPS
 /* Diagnostic build only (not declared in include/bitnet_hip.h, absent from the
  * production library): device buffer of 8 x u64 per workgroup for in-kernel stamps. */

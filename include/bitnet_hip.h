@@ -316,6 +316,14 @@ int bitnet_hip_logits_f16_dev(const void *table_f16_dev, const float *x_dev, con
 int bitnet_hip_argmax_dev(const float *v_dev, size_t n, void *scratch_dev, size_t n_workgroups,
                           int32_t *token_dev, void *stream);
 
+/* ---- measurement aid -------------------------------------------------------
+ * Measured HBM read ceiling of the device (quote the roofline fraction against the vendor
+ * figure AND a measured stream ceiling): a read-only streaming kernel (non-temporal 16-byte loads, one
+ * workgroup round per 2 MiB) over `bytes` of freshly written device memory (bytes >= 1 GiB keeps L2 and
+ * the 256 MB MALL out of it), `iters` timed passes with HIP events on the given stream.  Writes the
+ * best pass in GB/s (1e9 B/s) to *best_gbs and the mean to *mean_gbs.  Allocates and frees its buffer. */
+int bitnet_hip_hbm_read_ceiling(size_t bytes, int iters, double *best_gbs, double *mean_gbs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,3 +339,10 @@ def test_full_size_linearity_and_row_independence(hip, pkg):
             assert np.array_equal(y2.cpu().numpy(), y[0, r0:r1])
             hip.weights_free(h)
             hip.weights_free(h2)
+
+
+@pytest.mark.gpu
+def test_measured_read_ceiling_is_plausible(hip):
+    """bitnet_hip_hbm_read_ceiling: a read-only stream over 1 GiB lands between 2 and 8.2 TB/s on an MI355X."""
+    best, mean = hip.hbm_read_ceiling(1 << 30, 5)
+    assert 2000.0 < mean <= best < 8200.0, (best, mean)
