@@ -43,6 +43,7 @@ typedef float v4fl __attribute__((ext_vector_type(4)));
 
 // Weight bytes are read ONCE per launch by ONE CU: non-temporal loads keep them from displacing
 // the activation vectors in L2 / Infinity Cache and land sooner (MI355X_MICROARCH.md, nt-weights).
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint4 load_nt16(const void *p) {
     const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
     return uint4{v[0], v[1], v[2], v[3]};
@@ -176,7 +177,9 @@ template <int NW, int RING, int NV, int LN, int BS32>
 __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform: in an SGPR, so the tile / K-range index math and the load bases run on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     // several activation rows (prompt rows of a format the tiled matmul does not take): grid.y walks them
     const float *px = p.x + (size_t)blockIdx.y * p.cols;
@@ -204,6 +207,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     const int nvec = p.cols >> 2;  // cols % 4 == 0
 
     // ---- 1. activations first (vmcnt retires in order; these come from L2) ---------------
+    // byte offsets in 32 bits from a uniform base (scalar base + one VGPR offset per load); clamped to the
+    // row's last float4 so that a short range / ragged row re-reads valid memory
+    const uint32_t last_vec = 16u * (uint32_t)(nvec - 1), xo0 = 1024u * (uint32_t)b0 + 16u * (uint32_t)lane;
     float4 xr[RING];
     float4 sx[NV], sg[NV], gr[LN == 2 ? RING : 1];
     if (LN == 1) {
@@ -221,23 +227,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         // for the statistics (only needed in the epilogue); all ahead of the weight stream
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
-            const int idx = (b0 + j) * 64 + lane;
-            const int ci = idx < nvec ? idx : nvec - 1;
-            xr[j] = *reinterpret_cast<const float4 *>(px + 4 * ci);
-            gr[j] = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci);
+            const uint32_t o = umin32(xo0 + 1024u * j, last_vec);
+            xr[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(px) + o);
+            gr[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.ln_gamma) + o);
         }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + NT * i;
-            sx[i] = *reinterpret_cast<const float4 *>(px + 4 * (idx < nvec ? idx : nvec - 1));
-        }
+        for (int i = 0; i < NV; ++i)
+            sx[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(px) + umin32(16u * (uint32_t)(tid + NT * i), last_vec));
     } else {
 #pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            const int idx = (b0 + j) * 64 + lane;
-            const int ci = idx < nvec ? idx : nvec - 1;
-            xr[j] = *reinterpret_cast<const float4 *>(px + 4 * ci);
-        }
+        for (int j = 0; j < RING; ++j)
+            xr[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(px) + umin32(xo0 + 1024u * j, last_vec));
     }
 
     // ---- 2. weight tiles: RING 1-KiB tiles in flight per wave ------------------------------
@@ -326,9 +326,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         }
     }
     float am = 0.0f;
+    // wave-uniform: a full range of whole 256-column blocks needs no masking at all
+    const bool ragged = b1 - b0 < RING || b1 * 64 > nvec;
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
-        if (!(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
+        if (ragged && !(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
         am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[j].x), fabsf(xr[j].y))), fmaxf(fabsf(xr[j].z), fabsf(xr[j].w)));
     }
     am = wave_max_f(am);  // this wave's K range only: the scale is per wave
