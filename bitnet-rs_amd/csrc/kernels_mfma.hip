@@ -79,6 +79,7 @@ struct MfmaArgs {
     uint32_t lut;
     int ksplit;            // 1, 2, 4 or 8 K ranges per row tile (waves of one workgroup)
     int ks_log2;           // log2(ksplit): the index math ahead of the first load uses shifts, not divisions
+    double inv_cols;       // 1.0 / cols (LayerNorm statistics)
     const float *x;        // [mt, cols]
     float *y;              // [mt, rows]  (silu_mul: [mt, rows/2]); activation row blockIdx.y
     int out_rows;          // row stride of y
@@ -147,8 +148,21 @@ __device__ __forceinline__ v4i decode16(uint32_t w, uint32_t lut) {
 // Adding 0x808080 turns the three low digits into the UNSIGNED bytes of the sum (d_i + 128, the carries are the
 // adder's own), the top byte is already d3; flipping the three added bits back gives the signed digits:
 //     bytes of (q + 0x00808080) ^ 0x00808080  =  d0, d1, d2, d3        (two instructions per element)
+// round(v * sc) to the nearest integer in ONE instruction: v_cvt_rpi_i32_f32 = floor(x + 0.5) (ties go up
+// instead of to even; |error| <= 0.5 either way, and the kernel is VALU bound)
+__device__ __forceinline__ int cvt_rpi(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// max(|a|, |b|, m) in one instruction (the source modifiers do the fabs)
+__device__ __forceinline__ float max3_abs(float a, float b, float m) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
 __device__ __forceinline__ uint32_t digits4(float v, float sc) {
-    return ((uint32_t)__float2int_rn(v * sc) + 0x00808080u) ^ 0x00808080u;
+    return ((uint32_t)cvt_rpi(v * sc) + 0x00808080u) ^ 0x00808080u;
 }
 // 4 x 4 byte transpose: element dwords e0..e3 (byte i = digit i) -> plane dwords d0..d3 (byte b = element b)
 __device__ __forceinline__ void digit_planes(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t &d0, uint32_t &d1,
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
         if (ragged && !(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(xr[j].x), fabsf(xr[j].y))), fmaxf(fabsf(xr[j].z), fabsf(xr[j].w)));
+        am = max3_abs(xr[j].z, xr[j].w, max3_abs(xr[j].x, xr[j].y, am));
     }
     am = wave_max_f(am);  // this wave's K range only: the scale is per wave
     BH_STAMP(2);
@@ -449,7 +463,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         for (int j = 0; j < 4; ++j) part[wave * 16 + 4 * g + j] = f[j];
     }
     __syncthreads();
-    double ln_mean = 0.0, ln_denom = 1.0;
+    // only the storing threads (the first tiles_per_wg * 16, i.e. the first wave or two) go on: the other
+    // waves would repeat the row statistics' f64 arithmetic on the same SIMDs for nothing
+    if (wave * 64 >= tiles_per_wg * 16) return;
+    double ln_mean = 0.0, ln_rdenom = 1.0;
     if (LN == 2) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -457,10 +474,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             s1 += stat[2 * w];
             s2 += stat[2 * w + 1];
         }
-        const double mean_d = s1 / (double)p.cols;
-        const double var_d = s2 / (double)p.cols - mean_d * mean_d;
+        const double mean_d = s1 * p.inv_cols;  // 1/cols from the host: no f64 division sequences in the kernel
+        const double var_d = s2 * p.inv_cols - mean_d * mean_d;
         ln_mean = (double)(float)mean_d;                                              // the f32 mean the prologue form subtracts
-        ln_denom = (double)sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+        const double denom = (double)sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+        double r = __builtin_amdgcn_rcp(denom);  // v_rcp_f64 + two Newton steps: 1/denom to the last bit or so
+        r = r * (2.0 - denom * r);
+        ln_rdenom = r * (2.0 - denom * r);
     }
     if (!p.silu_mul) {
         if (tid < tiles_per_wg * 16) {
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
             if (row < p.rows) {
                 float v = 0.0f;
                 for (int kp = 0; kp < p.ksplit; ++kp) v += part[((tl << p.ks_log2) + kp) * 16 + r];
-                if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) / ln_denom);
+                if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) * ln_rdenom);
                 if (pres) v += pres[row];
                 py[row] = v;
             }
@@ -489,8 +509,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 }
                 if (LN == 2) {  // stored rows: (gate tile, up tile) pairs
                     const int t0 = blockIdx.x * tiles_per_wg + 2 * pl;
-                    gv = (float)(((double)gv - ln_mean * (double)p.ln_g[16 * t0 + r]) / ln_denom);
-                    uv = (float)(((double)uv - ln_mean * (double)p.ln_g[16 * (t0 + 1) + r]) / ln_denom);
+                    gv = (float)(((double)gv - ln_mean * (double)p.ln_g[16 * t0 + r]) * ln_rdenom);
+                    uv = (float)(((double)uv - ln_mean * (double)p.ln_g[16 * (t0 + 1) + r]) * ln_rdenom);
                 }
                 py[row] = gv / (1.0f + expf(-gv)) * uv;
             }
@@ -543,6 +563,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     const int nw = (getenv("BITNET_HIP_NW16") && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
     a.ks_log2 = a.ksplit == 8 ? 3 : a.ksplit == 4 ? 2 : a.ksplit == 2 ? 1 : 0;
+    a.inv_cols = 1.0 / (double)w.cols;
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
     a.ln_g = (fu.ln_gamma && w.ln_g && w.ln_gamma_bound == fu.ln_gamma) ? w.ln_g : nullptr;
