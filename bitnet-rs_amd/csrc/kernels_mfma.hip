@@ -161,6 +161,17 @@ __device__ __forceinline__ float max3_abs(float a, float b, float m) {
     asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
     return r;
 }
+// a * (f16 half of h) + c in f32
+__device__ __forceinline__ float fma_mix_lo(float a, uint32_t h, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, uint32_t h, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t digits4(float v, float sc) {
     return ((uint32_t)cvt_rpi(v * sc) + 0x00808080u) ^ 0x00808080u;
 }
@@ -391,9 +402,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 if (m & 1) {
                     float4 sv;
                     if (BS32 == 2) {
-                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                        const h2 a01 = __builtin_bit_cast(h2, m == 1 ? s_h[j].x : s_h[j].z), a23 = __builtin_bit_cast(h2, m == 1 ? s_h[j].y : s_h[j].w);
-                        sv = float4{(float)a01[0], (float)a01[1], (float)a23[0], (float)a23[1]};
+                        // f16 scales go into the fma as they are (v_fma_mix_f32: f32 * f16 + f32), no conversions
+                        const uint32_t a01 = m == 1 ? s_h[j].x : s_h[j].z, a23 = m == 1 ? s_h[j].y : s_h[j].w;
+                        facc[0] = fma_mix_lo((float)acc[0], a01, facc[0]);
+                        facc[1] = fma_mix_hi((float)acc[1], a01, facc[1]);
+                        facc[2] = fma_mix_lo((float)acc[2], a23, facc[2]);
+                        facc[3] = fma_mix_hi((float)acc[3], a23, facc[3]);
+                        acc = (v4i){0, 0, 0, 0};
+                        continue;
                     } else {
                         sv = m == 1 ? s_lo[j] : s_hi[j];
                     }
