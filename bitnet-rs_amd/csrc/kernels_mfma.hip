@@ -9,7 +9,7 @@
 // and v_mfma_i32_16x16x64_i8 does every multiply-add.
 //
 // Exactness: activations are converted once per launch to 30-bit fixed point with
-// one power-of-two scale per activation row (q = rint(x * 2^(29-E)), |q| <= 2^30)
+// one power-of-two scale per activation row (q = floor(x * 2^(29-E) + 1/2), |q| <= 2^30)
 // and split into four balanced base-256 digits d0..d3 in [-128,127].  The four
 // digit planes are four B-matrix columns of the MFMA, so
 //     sum_k w[r,k] * x[k]  =  2^(E-29) * sum_d 256^d * (sum_k w[r,k] * d_d[k])
