@@ -59,43 +59,47 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     const int kvh = blockIdx.x, pc = blockIdx.y, j0 = pc * kAttnChunk;
     if (j0 >= t_k) return;  // chunk beyond the context (the grid is sized for max_pos)
     __shared__ __attribute__((aligned(16))) float qs[kMaxGroup * kD];
-    __shared__ float kn[kD], vn[kD];
+    __shared__ __attribute__((aligned(16))) float kn[kD];
+    __shared__ float vn[kD];
     __shared__ float partial[4][kAttnChunk][kMaxGroup];
     // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
     // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
     __shared__ __attribute__((aligned(16))) float sc[kMaxGroup][2][kAttnChunk / 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: LDS / cache bases on the scalar unit
     const int group = n_heads / n_kv, half = kD / 2;
-    const bool owns_new = pos >= j0 && pos < j0 + kAttnChunk;
+    // The chunk that holds the new token is also the only partial one (pos in [j0, j0 + 64)  <=>  t_k - j0 <= 64).
+    // Workgroup-uniform, so everything that treats the new token or the tail sits behind ONE scalar branch
+    // and the other chunks run straight-line code (per-element selects around LDS reads cost an exec-mask
+    // branch each: 64 of them were a third of this kernel's instructions).
+    const bool last = t_k - j0 <= kAttnChunk;
     const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
     float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos);  // [chunk][D][64]
     float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos);  // [max_pos][D]
     // ---- the few loads RoPE needs go first (vmcnt retires in order: behind the 64 cache loads they
     //      would only count as arrived once the whole K/V chunk has) ------------------------------------
     //      All unconditional (clamped indices): a load under a branch makes hipcc wait at the join.
-    const int rg = tid >> 6, rj = tid & 63;  // RoPE on q: 4 heads x 64 rotation pairs = 256 threads
+    const int rg = wave, rj = lane;  // RoPE on q: 4 heads x 64 rotation pairs = 256 threads
     const float *q_raw = qkv + (size_t)(kvh * group + (rg < group ? rg : group - 1)) * kD;
     const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
     const float rs = sr[rj], rc = cr[rj], rq0 = q_raw[rj], rq1 = q_raw[half + rj];       // q: pair rj of head rg
     const float rk0 = k_raw[rj], rk1 = k_raw[half + rj];                                  // new key: pair rj (threads < 64 use it)
     const float rv = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid & 127)];  // new value: dim tid & 127
     __builtin_amdgcn_sched_barrier(0);  // these seven requests first, then the cache stream
-    // ---- every cache load of this thread is issued up front (none depends on q): the K
-    //      slice for the score pass (lane = position) and the V column for the P.V pass
-    //      (lane = dim); clamped addresses, masked later, so the loads are unconditional ----
+    // ---- every cache load of this thread is issued up front (none depends on q): the K slice for the
+    //      score pass (lane = position) and the V column for the P.V pass (lane = dim).  Uniform base + one
+    //      lane offset + immediates, no clamping: the whole 64-position tile is inside the allocation (the cache
+    //      is padded to whole chunks); positions at or past the new token hold stale bytes, discarded below ----
     float kv[32], vv[kAttnChunk / 2];
     {
-        const int j = j0 + lane, jc = j < pos ? j : (pos > 0 ? pos - 1 : 0);
-        const float *kp = kt + kidx(32 * wave, jc);
+        const float *kp = kt + ((size_t)pc * kD + 32 * wave) * 64 + lane;  // kidx(32 * wave, j0 + lane)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + (size_t)i * 64);  // cache bytes are read once per token
-        // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions jj = hp, hp+2, ...
-        const int d = tid & 127, hp = tid >> 7;
+        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + i * 64);  // cache bytes are read once per token
+        // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions j0 + hp, j0 + hp + 2, ...:
+        // element (j0 + 2 i + hp) * D + d = j0 * D + tid + 2 i D
+        const float *vp = vc + (size_t)j0 * kD + tid;
 #pragma unroll
-        for (int i = 0; i < kAttnChunk / 2; ++i) {
-            const int jj = j0 + 2 * i + hp, jcl = jj < pos ? jj : (pos > 0 ? pos - 1 : 0);
-            vv[i] = __builtin_nontemporal_load(vc + (size_t)jcl * kD + d);
-        }
+        for (int i = 0; i < kAttnChunk / 2; ++i) vv[i] = __builtin_nontemporal_load(vp + i * 2 * kD);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep hipcc from moving the RoPE arithmetic (and its wait) up between the loads
     // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         kn[rj] = a;
         kn[half + rj] = b;
         vn[tid & 127] = rv;
-        if (owns_new) {
+        if (last) {
             if (tid < half) {
                 kt[kidx(tid, pos)] = a;  // append (transposed)
                 kt[kidx(half + tid, pos)] = b;
@@ -128,9 +132,17 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     __syncthreads();
     // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
     {
-        const int j = j0 + lane;
+        if (last) {  // the new token's key comes from LDS (its cache slot was read before it was written)
+            const bool isnew = j0 + lane == pos;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = (j < pos) ? kv[i] : (j == pos ? kn[32 * wave + i] : 0.0f);
+            for (int i = 0; i < 32; i += 4) {
+                const float4 k4 = *reinterpret_cast<const float4 *>(kn + 32 * wave + i);
+                kv[i] = isnew ? k4.x : kv[i];
+                kv[i + 1] = isnew ? k4.y : kv[i + 1];
+                kv[i + 2] = isnew ? k4.z : kv[i + 2];
+                kv[i + 3] = isnew ? k4.w : kv[i + 3];
+            }
+        }
         float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 32; i += 4) {
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     }
     __syncthreads();
     // ---- chunk-local softmax pieces: wave g owns head g, lane = position ---------------------
+    // (positions past the context carried stale keys: their scores, whatever they are, are replaced here)
     const float scale = 1.0f / sqrtf((float)kD);
     float m_c, l_c;
     {
@@ -164,23 +177,25 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
     {
         const int d = tid & 127, hp = tid >> 7;
-        const int cnt = t_k - j0 < kAttnChunk ? t_k - j0 : kAttnChunk;
+        if (last) {  // the new token's value from LDS; stale values past the context become exact zeros (0 * NaN is NaN)
+            const int cnt = t_k - j0;
+            const float vnd = vn[d];
+#pragma unroll
+            for (int i = 0; i < kAttnChunk / 2; ++i) {
+                const int jj = 2 * i + hp;
+                vv[i] = jj < cnt ? (j0 + jj == pos ? vnd : vv[i]) : 0.0f;
+            }
+        }
         float a[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < kAttnChunk / 2; i += 4) {
-            float v4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jj = 2 * (i + u) + hp;
-                v4[u] = jj < cnt ? (j0 + jj == pos ? vn[d] : vv[i + u]) : 0.0f;
-            }
 #pragma unroll
             for (int g = 0; g < kMaxGroup; ++g) {
                 const float4 w = *reinterpret_cast<const float4 *>(&sc[g][hp][i]);
-                a[g] += w.x * v4[0];
-                a[g] += w.y * v4[1];
-                a[g] += w.z * v4[2];
-                a[g] += w.w * v4[3];
+                a[g] += w.x * vv[i];
+                a[g] += w.y * vv[i + 1];
+                a[g] += w.z * vv[i + 2];
+                a[g] += w.w * vv[i + 3];
             }
         }
         // the two position parities meet through LDS (reuse the score partials buffer)
