@@ -24,6 +24,7 @@ constexpr int kMaxGroup = 4;
 constexpr int kD = 128;
 // per (kv head, chunk) record in the scratch buffer: m[4], l[4], o[4][128]
 constexpr int kRec = 2 * kMaxGroup + kMaxGroup * kD;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // K cache element (dim d, position pos) of one KV head
 __device__ __forceinline__ size_t kidx(int d, int pos) { return ((size_t)(pos >> 6) * kD + d) * 64 + (pos & 63); }
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
     // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
     __shared__ __attribute__((aligned(16))) float sc[kMaxGroup][2][kAttnChunk / 2];
+    __shared__ __attribute__((aligned(16))) float enew[kMaxGroup];  // softmax weight of the new token (its chunk only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: LDS / cache bases on the scalar unit
     const int group = n_heads / n_kv, half = kD / 2;
@@ -131,32 +133,34 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     }
     __syncthreads();
     // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
+    // Two partial sums per head (even / odd dims) so that each v_pk_fma_f32 takes an adjacent (q[d], q[d+1]) pair
+    // from one LDS read and an adjacent (k[d], k[d+1]) register pair: no operand shuffling.
     {
         if (last) {  // the new token's key comes from LDS (its cache slot was read before it was written)
             const bool isnew = j0 + lane == pos;
 #pragma unroll
             for (int i = 0; i < 32; i += 4) {
-                const float4 k4 = *reinterpret_cast<const float4 *>(kn + 32 * wave + i);
+                float4 k4 = *reinterpret_cast<const float4 *>(kn + 32 * wave + i);
+                asm volatile("" : "+v"(k4.x), "+v"(k4.y), "+v"(k4.z), "+v"(k4.w));  // read for all lanes, then select: no exec-mask branch
                 kv[i] = isnew ? k4.x : kv[i];
                 kv[i + 1] = isnew ? k4.y : kv[i + 1];
                 kv[i + 2] = isnew ? k4.z : kv[i + 2];
                 kv[i + 3] = isnew ? k4.w : kv[i + 3];
             }
         }
-        float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+        v2f acc[kMaxGroup] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
         for (int i = 0; i < 32; i += 4) {
+            const v2f k01 = {kv[i], kv[i + 1]}, k23 = {kv[i + 2], kv[i + 3]};
 #pragma unroll
             for (int g = 0; g < kMaxGroup; ++g) {
                 const float4 q4 = *reinterpret_cast<const float4 *>(qs + g * kD + 32 * wave + i);
-                acc[g] += q4.x * kv[i];
-                acc[g] += q4.y * kv[i + 1];
-                acc[g] += q4.z * kv[i + 2];
-                acc[g] += q4.w * kv[i + 3];
+                acc[g] = __builtin_elementwise_fma((v2f){q4.x, q4.y}, k01, acc[g]);
+                acc[g] = __builtin_elementwise_fma((v2f){q4.z, q4.w}, k23, acc[g]);
             }
         }
 #pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) partial[wave][lane][g] = acc[g];
+        for (int g = 0; g < kMaxGroup; ++g) partial[wave][lane][g] = acc[g][0] + acc[g][1];
     }
     __syncthreads();
     // ---- chunk-local softmax pieces: wave g owns head g, lane = position ---------------------
@@ -170,39 +174,45 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         m_c = awave_max(s);
         const float e = j < t_k ? expf(s - m_c) : 0.0f;
         l_c = awave_sum(e);
-        sc[g][lane & 1][lane >> 1] = e;
+        // the new token's value is not in the cache registers: its weight goes aside (enew) and its slot gets 0
+        sc[g][lane & 1][lane >> 1] = j == pos ? 0.0f : e;
+        if (j == pos) enew[g] = e;
     }
     __syncthreads();
     // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
     {
         const int d = tid & 127, hp = tid >> 7;
-        if (last) {  // the new token's value from LDS; stale values past the context become exact zeros (0 * NaN is NaN)
-            const int cnt = t_k - j0;
-            const float vnd = vn[d];
-#pragma unroll
-            for (int i = 0; i < kAttnChunk / 2; ++i) {
-                const int jj = 2 * i + hp;
-                vv[i] = jj < cnt ? (j0 + jj == pos ? vnd : vv[i]) : 0.0f;
-            }
-        }
-        float a[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // Cache slots at or past the new token hold stale bytes; their weights are exact zeros (the new token's own
+        // goes through enew), and 0 * finite = 0: the caches must never hold NaN / Inf bit patterns, i.e. be
+        // zero-filled before first use (include/bitnet_hip.h) -- then this loop needs no masking at all.
+        v2f a[kMaxGroup] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
         for (int i = 0; i < kAttnChunk / 2; i += 4) {
+            const v2f v01 = {vv[i], vv[i + 1]}, v23 = {vv[i + 2], vv[i + 3]};
 #pragma unroll
             for (int g = 0; g < kMaxGroup; ++g) {
                 const float4 w = *reinterpret_cast<const float4 *>(&sc[g][hp][i]);
-                a[g] += w.x * vv[i];
-                a[g] += w.y * vv[i + 1];
-                a[g] += w.z * vv[i + 2];
-                a[g] += w.w * vv[i + 3];
+                a[g] = __builtin_elementwise_fma((v2f){w.x, w.y}, v01, a[g]);
+                a[g] = __builtin_elementwise_fma((v2f){w.z, w.w}, v23, a[g]);
             }
+        }
+        float ar[kMaxGroup];
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) ar[g] = a[g][0] + a[g][1];
+        if (last && hp == 0) {  // the new token: value from LDS, weight from enew (one parity adds it)
+            const float vnd = vn[d];
+            const float4 en = *reinterpret_cast<const float4 *>(enew);
+            ar[0] += en.x * vnd;
+            ar[1] += en.y * vnd;
+            ar[2] += en.z * vnd;
+            ar[3] += en.w * vnd;
         }
         // the two position parities meet through LDS (reuse the score partials buffer)
         float *red = &partial[0][0][0];  // [2][kMaxGroup][kD] = 1024 floats = sizeof(partial)
         __syncthreads();                 // everyone is done reading partial[][][]
 #pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) red[(hp * kMaxGroup + g) * kD + d] = a[g];
+        for (int g = 0; g < kMaxGroup; ++g) red[(hp * kMaxGroup + g) * kD + d] = ar[g];
         __syncthreads();
 #pragma unroll
         for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = red[g * kD + d] + red[(kMaxGroup + g) * kD + d];

@@ -67,6 +67,9 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     for (auto &L : layers_) {
         const size_t n = (size_t)c_.n_kv_heads * (((size_t)c_.max_pos + 63) / 64 * 64) * D;  // whole 64-position tiles
         ok &= dalloc(&L.kcache, n) == hipSuccess && dalloc(&L.vcache, n) == hipSuccess;
+        // the decode attention reads whole 64-position tiles and multiplies slots past the context by exact zeros:
+        // they must hold finite bit patterns (include/bitnet_hip.h), so the caches start zero-filled
+        ok = ok && hipMemset(L.kcache, 0, n * sizeof(float)) == hipSuccess && hipMemset(L.vcache, 0, n * sizeof(float)) == hipSuccess;
         ok &= dalloc(&L.attn_norm, H) == hipSuccess && dalloc(&L.ffn_norm, H) == hipSuccess;
     }
     ok &= dalloc(&final_norm_, H) == hipSuccess;

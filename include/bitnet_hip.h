@@ -263,6 +263,9 @@ int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream);
  * the split-half layout (T:134-163) at position *pos_dev, append k,v to the f32 cache
  * (T:1171-1202; n_kv*ceil(max_pos/64)*64*head_dim floats each, layout private to this library: K is kept
  * transposed), GQA softmax attention over pos+1 keys.  head_dim 128, n_heads/n_kv <= 4.
+ * The caches must be ZERO-FILLED before their first use (hipMemset once after allocation): the kernel
+ * reads whole 64-position tiles and gives slots past the context an exact zero weight, which only cancels
+ * finite bit patterns (slots left over from an earlier, longer sequence are fine).
  * qkv_dev: [n_heads*D | n_kv*D | n_kv*D] raw projections; out_dev: [n_heads*D].
  * rope_sin/cos_dev: [max_pos, D/2] (crates/bitnet-rope/src/lib.rs:59-93). */
 int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_dev,
