@@ -54,8 +54,11 @@ __device__ __forceinline__ float awave_sum(float v) {
 
 __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
                                                       const float *__restrict__ rope_cos, float *__restrict__ kcache,
-                                                      float *__restrict__ vcache, int n_heads, int n_kv, int max_pos,
+                                                      float *__restrict__ vcache, int n_heads, int n_kv, int group, int max_pos,
                                                       const int *__restrict__ pos_ptr, float *__restrict__ scratch) {
+    // every kernel argument is requested together with pos_ptr: left alone hipcc fetches the others only behind
+    // the early exit, a second dependent scalar-load round trip for the workgroups that stay
+    asm volatile("" ::"s"(qkv), "s"(rope_sin), "s"(rope_cos), "s"(kcache), "s"(vcache), "s"(n_heads), "s"(n_kv), "s"(group), "s"(max_pos), "s"(scratch));
     const int pos = *pos_ptr, t_k = pos + 1;
     const int kvh = blockIdx.x, pc = blockIdx.y, j0 = pc * kAttnChunk;
     if (j0 >= t_k) return;  // chunk beyond the context (the grid is sized for max_pos)
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float enew[kMaxGroup];  // softmax weight of the new token (its chunk only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: LDS / cache bases on the scalar unit
-    const int group = n_heads / n_kv, half = kD / 2;
+    const int half = kD / 2;  // group = n_heads / n_kv comes as an argument (a runtime division costs ~25 instructions)
     // The chunk that holds the new token is also the only partial one (pos in [j0, j0 + 64)  <=>  t_k - j0 <= 64).
     // Workgroup-uniform, so everything that treats the new token or the tail sits behind ONE scalar branch
     // and the other chunks run straight-line code (per-element selects around LDS reads cost an exec-mask
@@ -226,24 +229,31 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
 // One workgroup per head: 8 thread groups walk the chunk records in parallel (chunk c -> group
 // c % 8), each merging (m, l, o) online; the 8 partial states meet through LDS.  Threads of a
 // group take 4 dims each (float4: one 512-byte record row per group and step).
-__global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_heads, int n_kv,
+__global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_kv, int group,
                                                       int n_chunks_max, const int *__restrict__ pos_ptr,
                                                       float *__restrict__ out) {
-    const int t_k = *pos_ptr + 1;
-    const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
-    const int kvh = blockIdx.x, g = blockIdx.y, group = n_heads / n_kv;
+    asm volatile("" ::"s"(scratch), "s"(n_kv), "s"(group), "s"(n_chunks_max), "s"(out));  // all arguments in one scalar-load round
+    const int kvh = blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, d4 = tid & 31, part = tid >> 5;
     __shared__ float sm[8], sl[8];
     __shared__ __attribute__((aligned(16))) float sa[8][kD];
     const float *base = scratch + (size_t)kvh * n_chunks_max * kRec;
-    float m = -INFINITY, l = 0.0f;
-    float4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int c = part; c < n_chunks; c += 8) {
+    // the first record of every thread group is requested before the position is known (one dependent round trip
+    // less); a group without a chunk reads a valid but stale record and drops it below
+    const float *rec0 = base + (size_t)(part < n_chunks_max ? part : n_chunks_max - 1) * kRec;
+    const float mc0 = rec0[g], lc0 = rec0[kMaxGroup + g];
+    const float4 o0 = *reinterpret_cast<const float4 *>(rec0 + 2 * kMaxGroup + g * kD + 4 * d4);
+    const int t_k = *pos_ptr + 1;
+    const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
+    const bool has = part < n_chunks;
+    float m = has ? mc0 : -INFINITY, l = has ? lc0 : 0.0f;
+    float4 a = {has ? o0.x : 0.f, has ? o0.y : 0.f, has ? o0.z : 0.f, has ? o0.w : 0.f};
+    for (int c = part + 8; c < n_chunks; c += 8) {
         const float *rec = base + (size_t)c * kRec;
         const float mc = rec[g], lc = rec[kMaxGroup + g];
         const float4 o = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
         const float m_new = fmaxf(m, mc);
-        const float s_old = expf(m - m_new), s_c = expf(mc - m_new);  // m = -inf at first: s_old = 0
+        const float s_old = expf(m - m_new), s_c = expf(mc - m_new);
         l = l * s_old + lc * s_c;
         a.x = a.x * s_old + o.x * s_c;
         a.y = a.y * s_old + o.y * s_c;
@@ -282,8 +292,8 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
     if (D != kD || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
     const int n_chunks = (max_pos + kAttnChunk - 1) / kAttnChunk;
     hipLaunchKernelGGL(k_attn_partial, dim3(n_kv, n_chunks), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
-                       vcache, n_heads, n_kv, max_pos, pos_ptr, scratch);
-    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_heads, n_kv, n_chunks, pos_ptr, out);
+                       vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
+    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_chunks, pos_ptr, out);
     return hipGetLastError();
 }
 
