@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float kn[kD];
     __shared__ float vn[kD];
     __shared__ float partial[4][kAttnChunk][kMaxGroup];
+    __shared__ float red[2 * kMaxGroup * kD];  // [position parity][head][dim] partial P.V sums
     // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
     // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
     __shared__ __attribute__((aligned(16))) float sc[kMaxGroup][2][kAttnChunk / 2];
@@ -211,9 +212,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             ar[2] += en.z * vnd;
             ar[3] += en.w * vnd;
         }
-        // the two position parities meet through LDS (reuse the score partials buffer)
-        float *red = &partial[0][0][0];  // [2][kMaxGroup][kD] = 1024 floats = sizeof(partial)
-        __syncthreads();                 // everyone is done reading partial[][][]
+        // the two position parities meet through LDS (a buffer of its own: reusing the score partials would cost a barrier)
 #pragma unroll
         for (int g = 0; g < kMaxGroup; ++g) red[(hp * kMaxGroup + g) * kD + d] = ar[g];
         __syncthreads();
