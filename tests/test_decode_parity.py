@@ -171,14 +171,18 @@ def test_decode_tokens_match_oracle(hip, pkg, oracle, synth, cfgd, n_prompt, n_n
     om.close()
 
 
-@pytest.mark.parametrize("max_pos,positions", [(512, [0, 63, 64, 300]), (8192, [0, 100, 3071, 3072, 5000, 8100])])
-def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions):
+@pytest.mark.parametrize("max_pos,positions,n_heads,n_kv", [
+    (512, [0, 1, 62, 63, 64, 65, 127, 128, 129, 300, 511], 8, 2),
+    (512, [0, 63, 64, 200], 4, 2),      # query group of 2
+    (512, [5, 64, 191], 3, 3),          # no grouping
+    (8192, [0, 100, 3071, 3072, 5000, 8100], 8, 2)])
+def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions, n_heads, n_kv):
     """One-token attention (RoPE + append + GQA softmax) at many context lengths against a f64 numpy
     reference; max_pos 8192 takes the long-context form (several 64-position chunks per workgroup,
     merged online)."""
-    n_heads, n_kv, D = 8, 2, 128
+    D = 128
     group = n_heads // n_kv
-    rng = np.random.default_rng(max_pos)
+    rng = np.random.default_rng(max_pos + n_heads)
     sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
     kc = rng.normal(0, 1, (n_kv, D, max_pos)).astype(np.float32)   # logical [kv][D][pos]; the device keeps 64-position tiles
     tiled = lambda a: np.ascontiguousarray(a.reshape(n_kv, D, max_pos // 64, 64).transpose(0, 2, 1, 3))
@@ -190,7 +194,11 @@ def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions):
     sin_d, cos_d = dev(sin), dev(cos)
     for pos in positions:
         qkv = rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32)
-        kcd, vcd = dev(tiled(kc)), dev(vc)
+        kc_in = kc.copy()
+        kc_in[:, :, pos:] = np.nan    # slots at / past the new token: stale KEYS may hold anything (their scores are replaced)
+        vc_in = vc.copy()
+        vc_in[:, pos:] *= 1e30        # stale VALUES only have to be finite (zero-filled-cache contract, include/bitnet_hip.h)
+        kcd, vcd = dev(tiled(kc_in)), dev(vc_in)
         out = torch_.full((n_heads * D,), float("nan"), device="cuda")
         pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
         hip.attention_decode_dev(dev(qkv), sin_d, cos_d, kcd, vcd, n_heads, n_kv, D, max_pos, pos_d, scratch, out)
