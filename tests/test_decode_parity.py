@@ -171,6 +171,47 @@ def test_decode_tokens_match_oracle(hip, pkg, oracle, synth, cfgd, n_prompt, n_n
     om.close()
 
 
+LONG = dict(hidden=512, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, ffn=1024, vocab=2048, max_pos=320, eps=1e-5, rope_theta=10000.0)
+
+
+def test_decode_across_chunk_boundaries_teacher_forced(hip, pkg, oracle, synth):
+    """Decode steps of a small model through the step graph, the context growing across the 64-position chunk
+    boundaries of the attention (64, 128, 192, 256): per-step logits against the oracle, every token forced to the
+    oracle's choice so that a near-tie cannot fork the two sequences."""
+    cfg = synth.ModelConfig(**LONG)
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    n_prompt, n_total = 10, 270
+    om = oracle.OracleModel(cfg, layers, glob, n_threads=8)
+    seq = list(synth.prompt(n_prompt, cfg.vocab))
+    o_logits = []
+    for p in range(n_total - 1):
+        _, logits, _ = om.step(seq[p])
+        o_logits.append(logits)
+        if p + 1 >= n_prompt:
+            seq.append(oracle.argmax(logits))
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w)
+    dec.set_globals(glob)
+    dec.reset()
+    dec.feed(seq)  # all forced
+    worst = 1.0
+    for p in range(n_total - 1):
+        dec.run(1, with_logits=True, use_graph=True)
+        c = cosine(dec.last_logits(), o_logits[p])
+        worst = min(worst, c)
+        assert c >= 0.9999, (p, c)
+    assert dec.position() == n_total - 1
+    # and the unforced greedy run picks the same tokens
+    dec.reset()
+    dec.feed(seq[:n_prompt])
+    dec.run(n_total - 1, with_logits=True, use_graph=True)
+    assert list(dec.history(n_total)) == [int(t) for t in seq], worst
+    dec.close()
+    om.close()
+
+
 @pytest.mark.parametrize("max_pos,positions,n_heads,n_kv", [
     (512, [0, 1, 62, 63, 64, 65, 127, 128, 129, 300, 511], 8, 2),
     (512, [0, 63, 64, 200], 4, 2),      # query group of 2
