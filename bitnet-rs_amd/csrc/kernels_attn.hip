@@ -247,18 +247,32 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
     const bool has = part < n_chunks;
     float m = has ? mc0 : -INFINITY, l = has ? lc0 : 0.0f;
     float4 a = {has ? o0.x : 0.f, has ? o0.y : 0.f, has ? o0.z : 0.f, has ? o0.w : 0.f};
-    for (int c = part + 8; c < n_chunks; c += 8) {
-        const float *rec = base + (size_t)c * kRec;
-        const float mc = rec[g], lc = rec[kMaxGroup + g];
-        const float4 o = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
-        const float m_new = fmaxf(m, mc);
-        const float s_old = expf(m - m_new), s_c = expf(mc - m_new);
-        l = l * s_old + lc * s_c;
-        a.x = a.x * s_old + o.x * s_c;
-        a.y = a.y * s_old + o.y * s_c;
-        a.z = a.z * s_old + o.z * s_c;
-        a.w = a.w * s_old + o.w * s_c;
-        m = m_new;
+    // long contexts: four further records per trip, all twelve loads requested before the first merge (a trip
+    // per record is a dependent L2 round trip each: 64 chunks at 4k context = 7 more rounds per group)
+    for (int c = part + 8; c < n_chunks; c += 32) {
+        float mc[4], lc[4];
+        float4 o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + 8 * u < n_chunks ? c + 8 * u : c;  // past the end: re-read this trip's first record, dropped below
+            const float *rec = base + (size_t)cu * kRec;
+            mc[u] = rec[g];
+            lc[u] = rec[kMaxGroup + g];
+            o[u] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c + 8 * u < n_chunks) {
+                const float m_new = fmaxf(m, mc[u]);
+                const float s_old = expf(m - m_new), s_c = expf(mc[u] - m_new);
+                l = l * s_old + lc[u] * s_c;
+                a.x = a.x * s_old + o[u].x * s_c;
+                a.y = a.y * s_old + o[u].y * s_c;
+                a.z = a.z * s_old + o[u].z * s_c;
+                a.w = a.w * s_old + o[u].w * s_c;
+                m = m_new;
+            }
+        }
     }
     if (d4 == 0) {
         sm[part] = m;
