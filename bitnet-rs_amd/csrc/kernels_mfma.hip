@@ -110,12 +110,22 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+// maximum of a NON-NEGATIVE float over the wave: on the bit patterns as unsigned integers (same order, no NaN
+// canonicalisation instructions), four DPP steps inside the rows of 16, row_bcast 15 / 31 across them, lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max_u(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o > v ? o : v;
+}
 __device__ __forceinline__ float wave_max_f(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+    uint32_t u = __float_as_uint(v);
+    u = dpp_max_u<0xB1, 0xf>(u);
+    u = dpp_max_u<0x4E, 0xf>(u);
+    u = dpp_max_u<0x141, 0xf>(u);
+    u = dpp_max_u<0x140, 0xf>(u);
+    u = dpp_max_u<0x142, 0xa>(u);  // row_bcast:15 into rows 1 and 3
+    u = dpp_max_u<0x143, 0xc>(u);  // row_bcast:31 into rows 2 and 3
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)u, 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_d<0xB1>(v);
@@ -353,11 +363,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     float am = 0.0f;
     // wave-uniform: a full range of whole 256-column blocks needs no masking at all
     const bool ragged = b1 - b0 < RING || b1 * 64 > nvec;
+    if (ragged) {  // one scalar branch, not one per block
 #pragma unroll
-    for (int j = 0; j < RING; ++j) {
-        if (ragged && !(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
-        am = max3_abs(xr[j].z, xr[j].w, max3_abs(xr[j].x, xr[j].y, am));
+        for (int j = 0; j < RING; ++j)
+            if (!(b0 + j < b1 && (b0 + j) * 64 + lane < nvec)) xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};  // outside the range / row
     }
+#pragma unroll
+    for (int j = 0; j < RING; ++j) am = max3_abs(xr[j].z, xr[j].w, max3_abs(xr[j].x, xr[j].y, am));
     am = wave_max_f(am);  // this wave's K range only: the scale is per wave
     BH_STAMP(2);
     // scale = 2^(29 - E), E = unbiased exponent of the maximum (clamped so the scale stays a
