@@ -346,3 +346,28 @@ def test_measured_read_ceiling_is_plausible(hip):
     """bitnet_hip_hbm_read_ceiling: a read-only stream over 1 GiB lands between 2 and 8.2 TB/s on an MI355X."""
     best, mean = hip.hbm_read_ceiling(1 << 30, 5)
     assert 2000.0 < mean <= best < 8200.0, (best, mean)
+
+
+def test_gemv_qk256_property(hip, pkg, oracle):
+    """Property test in the spirit of crates/bitnet-models/tests/qk256_property_tests.rs: any rows / cols (ragged
+    tails included), uniform codes, activations in [-10, 10] (qk256_avx2_correctness.rs:72-104) -- the device GEMV stays
+    within the reference's own scalar-vs-AVX2 tolerance of the scalar oracle, and is linear in the activations."""
+    from hypothesis import given, settings, strategies as st
+
+    _set(hip, pkg, "auto")
+
+    @settings(max_examples=40, deadline=None)
+    @given(rows=st.integers(1, 80), cols=st.integers(1, 2200), seed=st.integers(0, 2**31 - 1), scale=st.sampled_from([1e-3, 1.0, 250.0]))
+    def run(rows, cols, seed, scale):
+        stride = -(-cols // 256) * 64
+        rng = np.random.default_rng(seed)
+        qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+        x = (rng.uniform(-10, 10, cols) * scale).astype(np.float32)
+        got = hip.gemv_qk256(qs, x, rows, cols, stride)
+        want = oracle.gemv_qk256(qs, x, rows, cols, stride, impl="scalar")
+        assert np.all(approx_eq_with_len(got / scale, want / scale, cols)), (rows, cols, seed, scale)
+        # homogeneity: an exact power-of-two factor on x scales y exactly (fixed point with a power-of-two scale)
+        got2 = hip.gemv_qk256(qs, x * np.float32(4.0), rows, cols, stride)
+        assert np.array_equal(got2, got * np.float32(4.0)), (rows, cols, seed, scale)
+
+    run()
