@@ -127,6 +127,8 @@ class HipLib:
         L.bitnet_hip_embed_f16_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]
         L.bitnet_hip_advance_pos_dev.argtypes = [_vp, _vp]
         L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_attention_decode_partial_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
+        L.bitnet_hip_gemv_attn_merge_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
         L.bitnet_hip_attention_prefill_workspace_bytes.argtypes = [_sz, _sz, _sz]
         L.bitnet_hip_attention_prefill_workspace_bytes.restype = _sz
         L.bitnet_hip_attention_prefill_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]
@@ -352,6 +354,12 @@ class HipLib:
 
     def attention_decode_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_attention_decode_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _ptr(out), _vp(stream)))
+
+    def attention_decode_partial_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_decode_partial_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _vp(stream)))
+
+    def gemv_attn_merge_dev(self, h: int, scratch, n_heads: int, n_kv: int, max_pos: int, pos, y, residual=None, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_gemv_attn_merge_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _ptr(residual) if residual is not None else None, _vp(stream)))
 
     def logits_f16_dev(self, table, x, gamma, eps, hidden, vocab, logits, scratch, n_wg, token=None, pos=None, history=None, n_forced=None, stream: int = 0) -> None:
         opt = lambda t: _ptr(t) if t is not None else None

@@ -90,7 +90,7 @@ int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvF
     if ((kernel == BITNET_HIP_KERNEL_MFMA || kernel == BITNET_HIP_KERNEL_MFMA_TILED) && !mfma_supported(w))
         kernel = BITNET_HIP_KERNEL_VALU;
     if (kernel == BITNET_HIP_KERNEL_VALU && !valu_supported(w)) kernel = BITNET_HIP_KERNEL_EXACT;
-    if ((fu.ln_gamma || fu.residual || fu.silu_mul) && kernel != BITNET_HIP_KERNEL_MFMA && kernel != BITNET_HIP_KERNEL_MFMA_TILED)
+    if ((fu.ln_gamma || fu.residual || fu.silu_mul || fu.attn_rec) && kernel != BITNET_HIP_KERNEL_MFMA && kernel != BITNET_HIP_KERNEL_MFMA_TILED)
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "fused LayerNorm/residual needs the MFMA GEMV (shape %zux%zu unsupported)", w.rows, w.cols);
     hipError_t e;
     if (kernel == BITNET_HIP_KERNEL_MFMA_TILED || kernel == BITNET_HIP_KERNEL_MFMA) {
@@ -608,6 +608,45 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
     BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
                                   (int)max_pos, pos_dev, scratch, out, (hipStream_t)stream));
     return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                                            float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                            const int32_t *pos_dev, float *scratch, void *stream) {
+    BH_GUARD_BEGIN
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_partial_dev");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim != 128 || n_heads / n_kv_heads > 4)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
+                         head_dim, n_heads / n_kv_heads);
+    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                  (int)max_pos, pos_dev, scratch, nullptr, (hipStream_t)stream, false));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
+                                   size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *stream) {
+    BH_GUARD_BEGIN
+    Weights *w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!attn_scratch_dev || !pos_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_dev");
+    const size_t group = n_kv_heads ? n_heads / n_kv_heads : 0;
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0 || (group != 1 && group != 2 && group != 4) || w->cols != n_heads * 128)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_dev: needs cols == n_heads * 128 and a query group of 1, 2 or 4 (got %zu heads / %zu)",
+                         n_heads, n_kv_heads);
+    if (!mfma_supported(*w) || div_ceil(div_ceil(w->cols, 256), (size_t)8) > 2)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_dev: matrix shape %zux%zu not supported", w->rows, w->cols);
+    GemvFusion fu;
+    fu.residual = residual_dev;
+    fu.attn_rec = attn_scratch_dev;
+    fu.attn_pos = pos_dev;
+    fu.attn_chunks_max = (int)div_ceil(max_pos, (size_t)64);
+    fu.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
+    return run_gemv(*w, attn_scratch_dev, y_dev, 1, fu, (hipStream_t)stream);
     BH_GUARD_END
 }
 

@@ -22,8 +22,9 @@ namespace bitnet_hip {
 constexpr int kAttnChunk = 64;
 constexpr int kMaxGroup = 4;
 constexpr int kD = 128;
-// per (kv head, chunk) record in the scratch buffer: m[4], l[4], o[4][128]
-constexpr int kRec = 2 * kMaxGroup + kMaxGroup * kD;
+// per (kv head, chunk) record in the scratch buffer: (m, l)[4], o[4][128]   (kAttnRecFloats, common.hpp)
+constexpr int kRec = kAttnRecFloats;
+static_assert(kRec == 2 * kMaxGroup + kMaxGroup * kD, "record layout");
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // K cache element (dim d, position pos) of one KV head
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
         for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = red[g * kD + d] + red[(kMaxGroup + g) * kD + d];
     }
     if (lane == 0) {
-        rec[wave] = m_c;
-        rec[kMaxGroup + wave] = l_c;
+        rec[2 * wave] = m_c;
+        rec[2 * wave + 1] = l_c;
     }
 }
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
     // the first record of every thread group is requested before the position is known (one dependent round trip
     // less); a group without a chunk reads a valid but stale record and drops it below
     const float *rec0 = base + (size_t)(part < n_chunks_max ? part : n_chunks_max - 1) * kRec;
-    const float mc0 = rec0[g], lc0 = rec0[kMaxGroup + g];
+    const float mc0 = rec0[2 * g], lc0 = rec0[2 * g + 1];
     const float4 o0 = *reinterpret_cast<const float4 *>(rec0 + 2 * kMaxGroup + g * kD + 4 * d4);
     const int t_k = *pos_ptr + 1;
     const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
         for (int u = 0; u < 4; ++u) {
             const int cu = c + 8 * u < n_chunks ? c + 8 * u : c;  // past the end: re-read this trip's first record, dropped below
             const float *rec = base + (size_t)cu * kRec;
-            mc[u] = rec[g];
-            lc[u] = rec[kMaxGroup + g];
+            mc[u] = rec[2 * g];
+            lc[u] = rec[2 * g + 1];
             o[u] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
         }
 #pragma unroll
@@ -301,12 +302,15 @@ size_t attn_scratch_floats(int n_kv, int max_pos) {
 
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream) {
+                              float *scratch, float *out, hipStream_t stream, bool combine) {
     if (D != kD || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
     const int n_chunks = (max_pos + kAttnChunk - 1) / kAttnChunk;
     hipLaunchKernelGGL(k_attn_partial, dim3(n_kv, n_chunks), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
                        vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
-    hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_chunks, pos_ptr, out);
+    // combine == false: the chunk records stay in `scratch` for a consumer that merges them itself
+    // (launch_gemv_mfma with GemvFusion::attn_rec)
+    if (combine)
+        hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_chunks, pos_ptr, out);
     return hipGetLastError();
 }
 

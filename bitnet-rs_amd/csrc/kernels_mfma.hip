@@ -91,6 +91,10 @@ struct MfmaArgs {
     const float *stiles;   // optional f32 scales per (row, 32-block), tiled [tile][blk][q][cg][half][j]
     const uint16_t *stiles_h;  // the same as f16 when every scale is an f16 value (template BS32 == 2)
     int silu_mul;          // rows are (gate tile, up tile) pairs: y = silu(gate) * up
+    // MERGE: x is the decode attention output, merged here from its chunk records (GemvFusion::attn_rec)
+    const float *attn_rec;
+    const int *attn_pos;
+    int attn_chunks_max, attn_group_log2;
     unsigned long long *stamps;  // diagnostic builds only
 };
 
@@ -208,7 +212,13 @@ __device__ __forceinline__ void digit_planes(uint32_t e0, uint32_t e1, uint32_t 
 // so the waves quantise gamma*x of their own K range straight away and the row statistics are only
 // needed in the epilogue, behind the barrier that is there anyway (saves the two prologue barriers,
 // the normalised row's LDS round trip and ~1.4 us per launch).
-template <int NW, int RING, int NV, int LN, int BS32>
+// MERGE (LN == 0): the activation row is the decode attention's output and is assembled here from the per-chunk
+// records (m, l, un-normalised P.V) that k_attn_partial left in the scratch buffer -- softmax merge of up to 4
+// chunks per lane, for the 4 columns the lane quantises anyway -- instead of a separate combine launch (a kernel
+// boundary + a cross-XCD hand-over + its own chain: 3.2 us per layer).  Every workgroup needs the whole row, so
+// every workgroup reads every live record: n_chunks x 10 KB through the CU's 64 B/clk vector-memory path, which is
+// why this is for short contexts only (+3.3 % tokens/s at 3-4 chunks, break-even at 6-7).
+template <int NW, int RING, int NV, int LN, int BS32, int MERGE = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -247,6 +257,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     const uint32_t last_vec = 16u * (uint32_t)(nvec - 1), xo0 = 1024u * (uint32_t)b0 + 16u * (uint32_t)lane;
     float4 xr[RING];
     float4 sx[NV], sg[NV], gr[LN == 2 ? RING : 1];
+    const float *mrec[MERGE ? RING : 1];
+    int mo[MERGE ? RING : 1];
+    float2 mml[MERGE ? RING : 1][4];
+    float4 mov[MERGE ? RING : 1][4];
     if (LN == 1) {
         // LayerNorm needs the whole row: the workgroup reads x and gamma ONCE (each thread its
         // share) and hands the normalised row to the waves through LDS.
@@ -269,6 +283,22 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             sx[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(px) + umin32(16u * (uint32_t)(tid + NT * i), last_vec));
+    } else if (MERGE) {
+        // chunks 0..3 of this lane's head are requested before the position (hence the live chunk count) is known;
+        // dead records hold zeros or an earlier token's values (finite): only their m is masked below
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const uint32_t kf = umin32(xo0 + 1024u * j, last_vec) >> 2;  // first of this lane's 4 columns
+            const uint32_t h = kf >> 7, d = kf & 127u, kvh = h >> p.attn_group_log2, g = h & ((1u << p.attn_group_log2) - 1u);
+            mrec[j] = p.attn_rec + (size_t)kvh * p.attn_chunks_max * kAttnRecFloats + 2 * g;
+            mo[j] = 8 - 2 * g + g * 128 + d;  // from the (m, l) pair to the lane's 4 P.V values
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = c < p.attn_chunks_max ? c : p.attn_chunks_max - 1;
+                mml[j][c] = *reinterpret_cast<const float2 *>(mrec[j] + (size_t)cc * kAttnRecFloats);
+                mov[j][c] = *reinterpret_cast<const float4 *>(mrec[j] + (size_t)cc * kAttnRecFloats + mo[j]);
+            }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < RING; ++j)
@@ -295,12 +325,36 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         }
         if (BS32 == 2) s_h[j] = load_nt16(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
     }
+    int m_chunks = 0;
+    if (MERGE) m_chunks = (*p.attn_pos + 1 + 63) >> 6;  // live chunks, 1..4 (the caller switches to the combine kernel beyond 256 keys)
     // Every load of this wave is now requested.  Without the fence hipcc moves the activation
     // arithmetic (and its s_waitcnt) up between the weight loads, so that half of the weight stream is
     // only requested once the activations have arrived (~1 us later).
     __builtin_amdgcn_sched_barrier(0);
     BH_STAMP(1);
 
+    if (MERGE) {
+        // softmax merge of the chunk records: out = sum_c e^(m_c - M) o_c / sum_c e^(m_c - M) l_c  (k_attn_combine's value)
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mml[j][c].x = c < m_chunks ? mml[j][c].x : -INFINITY;
+                M = fmaxf(M, mml[j][c].x);
+            }
+            float L = 0.0f;
+            float4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float e = __expf(mml[j][c].x - M);
+                L += e * mml[j][c].y;
+                a.x += e * mov[j][c].x, a.y += e * mov[j][c].y, a.z += e * mov[j][c].z, a.w += e * mov[j][c].w;
+            }
+            const float rl = 1.0f / L;
+            xr[j] = float4{a.x * rl, a.y * rl, a.z * rl, a.w * rl};
+        }
+    }
     // ---- 3. prologue: [LayerNorm] -> fixed point -> this wave's digit planes --------------
     if (LN == 2) {
 #pragma unroll
@@ -600,6 +654,10 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.stiles = (bs32_any && !w.scales_f16) ? w.scale_tiles : nullptr;
     a.stiles_h = (bs32_any && w.scales_f16) ? w.scale_tiles_h : nullptr;
     a.silu_mul = fu.silu_mul ? 1 : 0;
+    a.attn_rec = fu.attn_rec;
+    a.attn_pos = fu.attn_pos;
+    a.attn_chunks_max = fu.attn_chunks_max;
+    a.attn_group_log2 = fu.attn_group_log2;
     a.stamps = g_mfma_stamps;
     const int tiles_per_wg = nw / a.ksplit;
     const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);
@@ -617,6 +675,10 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
         kfn = ln2 ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, 2, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, 2, 1> : k_gemv_mfma<NWv, RINGv, NVv, 2, 0>) \
               : ln ? (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, NVv, 1, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, NVv, 1, 1> : k_gemv_mfma<NWv, RINGv, NVv, 1, 0>) \
                    : (bs32 == 2 ? k_gemv_mfma<NWv, RINGv, 1, 0, 2> : bs32 == 1 ? k_gemv_mfma<NWv, RINGv, 1, 0, 1> : k_gemv_mfma<NWv, RINGv, 1, 0, 0>);
+    if (fu.attn_rec) {  // x merged from the decode attention's chunk records: the o-projection shape only
+        if (ln || m != 1 || nw != 8 || ring > 2 || w.cols % 128 != 0 || !fu.attn_pos || fu.attn_chunks_max < 1) return hipErrorInvalidValue;
+        kfn = bs32 == 2 ? k_gemv_mfma<8, 2, 1, 0, 2, 1> : bs32 == 1 ? k_gemv_mfma<8, 2, 1, 0, 1, 1> : k_gemv_mfma<8, 2, 1, 0, 0, 1>;
+    }
     BH_PICK(8, 2, 2) BH_PICK(8, 2, 4) BH_PICK(8, 3, 2) BH_PICK(8, 3, 4) BH_PICK(8, 4, 2) BH_PICK(8, 4, 4) BH_PICK(8, 5, 2) BH_PICK(8, 5, 4)
     BH_PICK(16, 2, 1) BH_PICK(16, 2, 2) BH_PICK(16, 3, 1) BH_PICK(16, 3, 2) BH_PICK(16, 4, 1) BH_PICK(16, 4, 2)
 #undef BH_PICK

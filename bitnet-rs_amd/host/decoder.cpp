@@ -52,6 +52,12 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     }
     stream_ = s;
     const size_t H = c_.hidden, D = c_.head_dim, half = D / 2;
+    {
+        // bitnet_hip_gemv_attn_merge_dev's shape limits (include/bitnet_hip.h)
+        const int group = c_.n_kv_heads > 0 ? c_.n_heads / c_.n_kv_heads : 0;
+        merge_ok_ = c_.head_dim == 128 && (group == 1 || group == 2 || group == 4) && c_.n_heads % c_.n_kv_heads == 0 &&
+                    (size_t)c_.n_heads * 128 <= 4096;
+    }
     bool ok = true;
     ok &= dalloc(&x_, H) == hipSuccess && dalloc(&x2_, H) == hipSuccess;
     ok &= dalloc(&qkv_, (size_t)(c_.n_heads + 2 * c_.n_kv_heads) * D) == hipSuccess;
@@ -59,7 +65,11 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     ok &= dalloc(&h_, (size_t)c_.ffn) == hipSuccess;
     ok &= dalloc(&logits_, (size_t)c_.vocab) == hipSuccess;
     ok &= hipMalloc(&scratch_, 8 * (size_t)logits_wgs_) == hipSuccess;
-    ok &= hipMalloc((void **)&attn_scratch_, bitnet_hip_attention_scratch_bytes((size_t)c_.n_kv_heads, (size_t)c_.max_pos)) == hipSuccess;
+    {
+        const size_t sb = bitnet_hip_attention_scratch_bytes((size_t)c_.n_kv_heads, (size_t)c_.max_pos);
+        // zero-filled: the merging o-projection reads records of chunks past the context (and gives them zero weight)
+        ok = ok && hipMalloc((void **)&attn_scratch_, sb) == hipSuccess && hipMemset(attn_scratch_, 0, sb) == hipSuccess;
+    }
     ok &= dalloc(&pos_, 1) == hipSuccess && dalloc(&n_forced_, 1) == hipSuccess && dalloc(&token_, 1) == hipSuccess;
     ok &= dalloc(&history_, (size_t)c_.max_pos + 2) == hipSuccess;
     ok &= dalloc(&rope_sin_, (size_t)c_.max_pos * half) == hipSuccess;
@@ -93,7 +103,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
 }
 
 Decoder::~Decoder() {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (graph_exec_[i]) hipGraphExecDestroy((hipGraphExec_t)graph_exec_[i]);
         if (graph_[i]) hipGraphDestroy((hipGraph_t)graph_[i]);
     }
@@ -250,17 +260,24 @@ int Decoder::position() {
 }
 
 // One decode step = TransformerModel::forward (T:1557-1597) on one token + logits.
-int Decoder::step_launches(bool with_logits) {
+int Decoder::step_launches(bool with_logits, bool merge_in_oproj) {
     void *s = stream_;
     const size_t H = c_.hidden;
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
     for (auto &L : layers_) {
         // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
         BCHK(bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, s));
-        BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                             (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
-        // o_proj + residual (T:542, T:1073)
-        BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
+        if (merge_in_oproj) {
+            // short contexts: one attention launch; the o-projection merges the chunk records itself
+            BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
+                                                         (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, s));
+            BCHK(bitnet_hip_gemv_attn_merge_dev(L.o, attn_scratch_, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.max_pos, pos_, x2_, x_, s));
+        } else {
+            BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
+                                                 (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            // o_proj + residual (T:542, T:1073)
+            BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
+        }
         // post_attention_layernorm -> gate, up -> silu(gate)*up (T:1104, T:756-781)
         BCHK(bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, s));
         // down_proj + residual (T:789, T:1125)
@@ -276,13 +293,13 @@ int Decoder::step_launches(bool with_logits) {
     return 0;
 }
 
-int Decoder::ensure_graph(bool with_logits) {
-    const int gi = with_logits ? 1 : 0;
+int Decoder::ensure_graph(bool with_logits, bool merge_in_oproj) {
+    const int gi = (merge_in_oproj ? 2 : 0) + (with_logits ? 1 : 0);
     if (graph_exec_[gi]) return 0;
     hipStream_t s = (hipStream_t)stream_;
     hipGraph_t g = nullptr;
     HCHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
-    const int rc = step_launches(with_logits);
+    const int rc = step_launches(with_logits, merge_in_oproj);
     const hipError_t e = hipStreamEndCapture(s, &g);
     if (rc != 0) {
         if (g) hipGraphDestroy(g);
@@ -308,10 +325,21 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
     }
     hipStream_t s = (hipStream_t)stream_;
+    // Steps whose context fits 4 attention chunks (position + 1 <= 256) take the form without the combine launch
+    // (BITNET_HOST_ATTN_MERGE=0 keeps the two-kernel attention everywhere); the host knows every step's position.
+    static const bool merge_env = !(getenv("BITNET_HOST_ATTN_MERGE") && atoi(getenv("BITNET_HOST_ATTN_MERGE")) == 0);
+    const bool merge_avail = merge_env && merge_ok_;
+    auto merge_at = [&](int pos) { return merge_avail && pos + 1 <= 256; };
     if (use_graph) {
         // first call: run one eager step so lazily raised kernel attributes exist before capture
-        int rc = ensure_graph(with_logits);
-        if (rc) return rc;
+        if (merge_at(p)) {
+            int rc = ensure_graph(with_logits, true);
+            if (rc) return rc;
+        }
+        if (!merge_at(p + n - 1)) {
+            int rc = ensure_graph(with_logits, false);
+            if (rc) return rc;
+        }
     }
     hipEvent_t e0, e1;
     HCHK(hipEventCreate(&e0));
@@ -319,9 +347,9 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
     HCHK(hipEventRecord(e0, s));
     for (int i = 0; i < n; ++i) {
         if (use_graph) {
-            HCHK(hipGraphLaunch((hipGraphExec_t)graph_exec_[with_logits ? 1 : 0], s));
+            HCHK(hipGraphLaunch((hipGraphExec_t)graph_exec_[(merge_at(p + i) ? 2 : 0) + (with_logits ? 1 : 0)], s));
         } else {
-            int rc = step_launches(with_logits);
+            int rc = step_launches(with_logits, merge_at(p + i));
             if (rc) return rc;
         }
     }

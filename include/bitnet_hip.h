@@ -273,6 +273,22 @@ int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_
                                     size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                     const int32_t *pos_dev, float *scratch_dev, float *out_dev,
                                     void *stream);
+/* Short contexts (at most 256 keys = 4 chunks of 64): the attention in ONE launch plus an output projection that
+ * merges the chunk results itself.  bitnet_hip_attention_decode_partial_dev = the first of the two kernels of
+ * bitnet_hip_attention_decode_dev (RoPE, KV append, per-chunk softmax pieces into scratch_dev; same arguments,
+ * no out_dev); bitnet_hip_gemv_attn_merge_dev(w, scratch, ...) = bitnet_hip_gemv_fused_dev(w, attention output,
+ * y, m = 1, no LayerNorm, residual) with the attention output assembled from those records on the fly (every
+ * workgroup of the projection reads every live record, n_chunks x 10 KB -- which is why this is for short
+ * contexts only; the caller falls back to bitnet_hip_attention_decode_dev + bitnet_hip_gemv_fused_dev once
+ * *pos_dev + 1 exceeds 256).  w: cols == n_heads * 128; query group 1, 2 or 4.  scratch_dev must be zero-filled
+ * before its first use (records of chunks past the context are read and given zero weight). */
+int bitnet_hip_attention_decode_partial_dev(const float *qkv_dev, const float *rope_sin_dev, const float *rope_cos_dev,
+                                            float *kcache_dev, float *vcache_dev, size_t n_heads, size_t n_kv_heads,
+                                            size_t head_dim, size_t max_pos, const int32_t *pos_dev, float *scratch_dev,
+                                            void *stream);
+int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
+                                   size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
+                                   const float *residual_dev, void *stream);
 /* The same attention for a whole prompt of seq_len tokens on a FRESH cache (positions
  * 0..seq_len-1): RoPE, cache append, causal GQA softmax attention (T:398-543 with the causal
  * mask T:452-470).  qkv_dev: [seq_len, n_heads*D + 2*n_kv*D]; out_dev: [seq_len, n_heads*D].

@@ -304,3 +304,45 @@ def test_layernorm_after_product_matches_prologue_form(hip, oracle, torch_, fmt)
         assert np.array_equal(y1.cpu().numpy(), y3.cpu().numpy())
         hip.weights_bind_ln(h, g2)  # unbind for the next round: gd no longer matches
     hip.weights_free(h)
+
+
+@pytest.mark.parametrize("n_heads,n_kv", [(8, 2), (4, 2), (20, 5), (3, 3)])
+def test_oproj_merging_the_attention_records_equals_combine_then_project(hip, pkg, oracle, torch_, n_heads, n_kv):
+    """bitnet_hip_attention_decode_partial_dev + bitnet_hip_gemv_attn_merge_dev (short contexts: no combine launch)
+    against bitnet_hip_attention_decode_dev + bitnet_hip_gemv_fused_dev on the same inputs, contexts of 1..4 chunks."""
+    D, max_pos = 128, 512
+    cols, rows = n_heads * D, 384
+    rng = np.random.default_rng(7 * n_heads + n_kv)
+    stride = -(-cols // 256) * 64
+    qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+    w = hip.weights_upload_qk256(qs, rows, cols, stride)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a)).cuda()
+    sin_d, cos_d = dev(sin), dev(cos)
+    sb = hip.c.bitnet_hip_attention_scratch_bytes(n_kv, max_pos)
+    for pos in (0, 1, 63, 64, 127, 128, 200, 255):
+        kc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
+        vc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
+        qkv = dev(rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32))
+        res = dev(rng.normal(0, 1, rows).astype(np.float32))
+        pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
+        # reference form: attention (two kernels) -> o-projection
+        k1, v1 = dev(kc), dev(vc)
+        scratch1 = torch_.zeros(sb // 4 + 16, device="cuda")
+        att = torch_.zeros(cols, device="cuda")
+        y1 = torch_.zeros(rows, device="cuda")
+        hip.attention_decode_dev(qkv, sin_d, cos_d, k1, v1, n_heads, n_kv, D, max_pos, pos_d, scratch1, att)
+        hip.gemv_fused_dev(w, att, y1, 1, residual=res)
+        # merged form
+        k2, v2 = dev(kc), dev(vc)
+        scratch2 = torch_.zeros(sb // 4 + 16, device="cuda")
+        # stale-but-finite records past the context (an earlier, longer sequence) must not matter
+        scratch2 += 3.0
+        y2 = torch_.zeros(rows, device="cuda")
+        hip.attention_decode_partial_dev(qkv, sin_d, cos_d, k2, v2, n_heads, n_kv, D, max_pos, pos_d, scratch2)
+        hip.gemv_attn_merge_dev(w, scratch2, n_heads, n_kv, max_pos, pos_d, y2, residual=res)
+        torch_.cuda.synchronize()
+        a, b = y1.cpu().numpy(), y2.cpu().numpy()
+        assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, np.max(np.abs(a))), (n_heads, n_kv, pos, np.max(np.abs(a - b)))
+        assert torch_.equal(k1, k2) and torch_.equal(v1, v2)  # the same cache append
+    hip.weights_free(w)
