@@ -127,6 +127,7 @@ class HipLib:
         L.bitnet_hip_embed_f16_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]
         L.bitnet_hip_advance_pos_dev.argtypes = [_vp, _vp]
         L.bitnet_hip_attention_decode_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_attention_decode_wide_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
         L.bitnet_hip_attention_decode_partial_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
         L.bitnet_hip_gemv_attn_merge_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]
         L.bitnet_hip_attention_prefill_workspace_bytes.argtypes = [_sz, _sz, _sz]
@@ -354,6 +355,9 @@ class HipLib:
 
     def attention_decode_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_attention_decode_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _ptr(out), _vp(stream)))
+
+    def attention_decode_wide_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_decode_wide_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _ptr(out), _vp(stream)))
 
     def attention_decode_partial_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_attention_decode_partial_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos, _ptr(pos), _ptr(scratch), _vp(stream)))

@@ -611,6 +611,23 @@ int bitnet_hip_attention_decode_dev(const float *qkv, const float *rope_sin, con
     BH_GUARD_END
 }
 
+int bitnet_hip_attention_decode_wide_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
+                                         float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                         const int32_t *pos_dev, float *scratch, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch || !out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_wide_dev");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim != 128 || n_heads / n_kv_heads > 4)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
+                         head_dim, n_heads / n_kv_heads);
+    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                  (int)max_pos, pos_dev, scratch, out, (hipStream_t)stream, true, 2));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                                             float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                             const int32_t *pos_dev, float *scratch, void *stream) {
@@ -628,6 +645,8 @@ int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_
     BH_GUARD_END
 }
 
+size_t bitnet_hip_attention_merge_max_keys(void) { return (size_t)4 * 64; }
+
 int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
                                    size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *stream) {
     BH_GUARD_BEGIN
@@ -644,7 +663,8 @@ int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scr
     fu.residual = residual_dev;
     fu.attn_rec = attn_scratch_dev;
     fu.attn_pos = pos_dev;
-    fu.attn_chunks_max = (int)div_ceil(max_pos, (size_t)64);
+    fu.attn_chunk_log2 = 6;
+    fu.attn_chunks_max = (int)div_ceil(max_pos, (size_t)1 << fu.attn_chunk_log2);
     fu.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
     return run_gemv(*w, attn_scratch_dev, y_dev, 1, fu, (hipStream_t)stream);
     BH_GUARD_END

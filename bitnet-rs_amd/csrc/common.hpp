@@ -83,10 +83,11 @@ struct GemvFusion {
     const float *residual = nullptr;  // y = residual + W x
     bool silu_mul = false;            // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     // x = the decode attention's output, merged from its chunk records by the GEMV itself (no combine launch):
-    // records of launch_attn_decode(..., combine = false); contexts of at most 4 chunks (256 positions)
+    // records of launch_attn_decode(..., combine = false); contexts of at most 4 records
     const float *attn_rec = nullptr;
     const int *attn_pos = nullptr;    // *attn_pos + 1 keys
     int attn_chunks_max = 0;          // records per KV head in the buffer
+    int attn_chunk_log2 = 6;          // positions per record = 1 << attn_chunk_log2
     int attn_group_log2 = 0;          // query heads per KV head = 1 << attn_group_log2
 };
 
@@ -120,8 +121,8 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
                             bool rms, hipStream_t stream);
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine = true);
-// decode attention chunk record (one per KV head and 64-position chunk) in the scratch buffer:
+                              float *scratch, float *out, hipStream_t stream, bool combine = true, int halves = 1);
+// decode attention chunk record (one per KV head and 64- or 128-position chunk) in the scratch buffer:
 // (m, l) per head of the query group [4][2], then the un-normalised P.V partial [4][128]
 constexpr int kAttnRecFloats = 8 + 4 * 128;
 size_t attn_scratch_floats(int n_kv, int max_pos);

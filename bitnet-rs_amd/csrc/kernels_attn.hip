@@ -53,86 +53,97 @@ __device__ __forceinline__ float awave_sum(float v) {
     return (arl(v, 0) + arl(v, 16)) + (arl(v, 32) + arl(v, 48));
 }
 
-__global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
-                                                      const float *__restrict__ rope_cos, float *__restrict__ kcache,
-                                                      float *__restrict__ vcache, int n_heads, int n_kv, int group, int max_pos,
-                                                      const int *__restrict__ pos_ptr, float *__restrict__ scratch) {
+// NH = 64-position halves per workgroup (256 threads each).  NH = 2: a workgroup covers 128 positions, its two halves
+// run the chunk algorithm side by side and meet in LDS, so there is ONE record per 128 positions: half as many
+// records for whoever merges them (the combine kernel, or the o-projection at short contexts) and, at 4k keys, 160
+// workgroups instead of 320 (one per CU instead of 64 CUs with two).
+template <int NH>
+__global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
+                                                           const float *__restrict__ rope_cos, float *__restrict__ kcache,
+                                                           float *__restrict__ vcache, int n_heads, int n_kv, int group, int max_pos,
+                                                           const int *__restrict__ pos_ptr, float *__restrict__ scratch) {
     // every kernel argument is requested together with pos_ptr: left alone hipcc fetches the others only behind
     // the early exit, a second dependent scalar-load round trip for the workgroups that stay
     asm volatile("" ::"s"(qkv), "s"(rope_sin), "s"(rope_cos), "s"(kcache), "s"(vcache), "s"(n_heads), "s"(n_kv), "s"(group), "s"(max_pos), "s"(scratch));
     const int pos = *pos_ptr, t_k = pos + 1;
-    const int kvh = blockIdx.x, pc = blockIdx.y, j0 = pc * kAttnChunk;
-    if (j0 >= t_k) return;  // chunk beyond the context (the grid is sized for max_pos)
+    const int kvh = blockIdx.x, pc = blockIdx.y;
+    if (pc * NH * kAttnChunk >= t_k) return;  // record beyond the context (the grid is sized for max_pos)
     __shared__ __attribute__((aligned(16))) float qs[kMaxGroup * kD];
     __shared__ __attribute__((aligned(16))) float kn[kD];
     __shared__ float vn[kD];
-    __shared__ float partial[4][kAttnChunk][kMaxGroup];
-    __shared__ float red[2 * kMaxGroup * kD];  // [position parity][head][dim] partial P.V sums
+    __shared__ float partial[NH][4][kAttnChunk][kMaxGroup];
+    __shared__ float red[NH][2 * kMaxGroup * kD];  // [half][position parity][head][dim] partial P.V sums
     // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
     // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
-    __shared__ __attribute__((aligned(16))) float sc[kMaxGroup][2][kAttnChunk / 2];
-    __shared__ __attribute__((aligned(16))) float enew[kMaxGroup];  // softmax weight of the new token (its chunk only)
+    __shared__ __attribute__((aligned(16))) float sc[NH][kMaxGroup][2][kAttnChunk / 2];
+    __shared__ __attribute__((aligned(16))) float enew[kMaxGroup];  // softmax weight of the new token (its half only)
+    __shared__ float hm[NH][kMaxGroup], hl[NH][kMaxGroup];          // per-half (m, l) for the merge (NH == 2)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: LDS / cache bases on the scalar unit
-    const int half = kD / 2;  // group = n_heads / n_kv comes as an argument (a runtime division costs ~25 instructions)
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: LDS / cache bases on the scalar unit
+    const int half = NH == 2 ? wave_all >> 2 : 0, wave = wave_all & 3, t4 = tid & 255;
+    const int chunk = pc * NH + half, j0 = chunk * kAttnChunk;
+    const bool live = j0 < t_k;  // NH == 2: the second half of the last record may lie past the context
+    const int hd = kD / 2;
     // The chunk that holds the new token is also the only partial one (pos in [j0, j0 + 64)  <=>  t_k - j0 <= 64).
-    // Workgroup-uniform, so everything that treats the new token or the tail sits behind ONE scalar branch
+    // Wave-uniform, so everything that treats the new token or the tail sits behind ONE scalar branch
     // and the other chunks run straight-line code (per-element selects around LDS reads cost an exec-mask
     // branch each: 64 of them were a third of this kernel's instructions).
-    const bool last = t_k - j0 <= kAttnChunk;
-    const float *sr = rope_sin + (size_t)pos * half, *cr = rope_cos + (size_t)pos * half;
+    const bool last = live && t_k - j0 <= kAttnChunk;
+    const float *sr = rope_sin + (size_t)pos * hd, *cr = rope_cos + (size_t)pos * hd;
     float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos);  // [chunk][D][64]
     float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos);  // [max_pos][D]
     // ---- the few loads RoPE needs go first (vmcnt retires in order: behind the 64 cache loads they
     //      would only count as arrived once the whole K/V chunk has) ------------------------------------
     //      All unconditional (clamped indices): a load under a branch makes hipcc wait at the join.
-    const int rg = wave, rj = lane;  // RoPE on q: 4 heads x 64 rotation pairs = 256 threads
+    const int rg = wave, rj = lane;  // RoPE on q: 4 heads x 64 rotation pairs = 256 threads (every half does it; half 0 stores)
     const float *q_raw = qkv + (size_t)(kvh * group + (rg < group ? rg : group - 1)) * kD;
     const float *k_raw = qkv + (size_t)n_heads * kD + (size_t)kvh * kD;
-    const float rs = sr[rj], rc = cr[rj], rq0 = q_raw[rj], rq1 = q_raw[half + rj];       // q: pair rj of head rg
-    const float rk0 = k_raw[rj], rk1 = k_raw[half + rj];                                  // new key: pair rj (threads < 64 use it)
-    const float rv = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (tid & 127)];  // new value: dim tid & 127
+    const float rs = sr[rj], rc = cr[rj], rq0 = q_raw[rj], rq1 = q_raw[hd + rj];        // q: pair rj of head rg
+    const float rk0 = k_raw[rj], rk1 = k_raw[hd + rj];                                   // new key: pair rj (threads < 64 use it)
+    const float rv = qkv[(size_t)(n_heads + n_kv) * kD + (size_t)kvh * kD + (t4 & 127)];  // new value: dim t4 & 127
     __builtin_amdgcn_sched_barrier(0);  // these seven requests first, then the cache stream
     // ---- every cache load of this thread is issued up front (none depends on q): the K slice for the
     //      score pass (lane = position) and the V column for the P.V pass (lane = dim).  Uniform base + one
     //      lane offset + immediates, no clamping: the whole 64-position tile is inside the allocation (the cache
-    //      is padded to whole chunks); positions at or past the new token hold stale bytes, discarded below ----
+    //      is padded to whole chunks, and a dead half re-reads its workgroup's first tile); positions at or past
+    //      the new token hold stale bytes, discarded below ----
     float kv[32], vv[kAttnChunk / 2];
     {
-        const float *kp = kt + ((size_t)pc * kD + 32 * wave) * 64 + lane;  // kidx(32 * wave, j0 + lane)
+        const int cl = live ? chunk : pc * NH, jl = cl * kAttnChunk;
+        const float *kp = kt + ((size_t)cl * kD + 32 * wave) * 64 + lane;  // kidx(32 * wave, jl + lane)
 #pragma unroll
         for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + i * 64);  // cache bytes are read once per token
-        // P.V: thread (d = tid & 127, half hp = tid >> 7) takes positions j0 + hp, j0 + hp + 2, ...:
-        // element (j0 + 2 i + hp) * D + d = j0 * D + tid + 2 i D
-        const float *vp = vc + (size_t)j0 * kD + tid;
+        // P.V: thread (d = t4 & 127, parity hp = t4 >> 7) takes positions jl + hp, jl + hp + 2, ...:
+        // element (jl + 2 i + hp) * D + d = jl * D + t4 + 2 i D
+        const float *vp = vc + (size_t)jl * kD + t4;
 #pragma unroll
         for (int i = 0; i < kAttnChunk / 2; ++i) vv[i] = __builtin_nontemporal_load(vp + i * 2 * kD);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep hipcc from moving the RoPE arithmetic (and its wait) up between the loads
-    // ---- RoPE on the group's queries (and, in the owning chunk, on the new key) ----------
-    {
+    // ---- RoPE on the group's queries (and, in the owning half, on the new key) ----------
+    if (half == 0) {
         float a = 0.0f, b = 0.0f;
         if (rg < group) {
             a = rq0 * rc - rq1 * rs;
             b = rq0 * rs + rq1 * rc;
         }
         qs[rg * kD + rj] = a;
-        qs[rg * kD + half + rj] = b;
+        qs[rg * kD + hd + rj] = b;
     }
-    // the new key / value go to LDS from EVERY thread of every workgroup (the four waves write the same
+    // the new key / value go to LDS from EVERY thread of every workgroup (all waves write the same
     // values): used only under a branch, hipcc sinks their loads behind the cache stream, where the
-    // in-order counter makes them as late as the last cache byte.  Only the owning chunk appends to the cache.
+    // in-order counter makes them as late as the last cache byte.  Only the owning half appends to the cache.
     {
         const float a = rk0 * rc - rk1 * rs, b = rk0 * rs + rk1 * rc;  // rotation pair rj of the new key
         kn[rj] = a;
-        kn[half + rj] = b;
-        vn[tid & 127] = rv;
+        kn[hd + rj] = b;
+        vn[t4 & 127] = rv;
         if (last) {
-            if (tid < half) {
-                kt[kidx(tid, pos)] = a;  // append (transposed)
-                kt[kidx(half + tid, pos)] = b;
-            } else if (tid >= 128) {
-                vc[(size_t)pos * kD + (tid - 128)] = rv;
+            if (t4 < hd) {
+                kt[kidx(t4, pos)] = a;  // append (transposed)
+                kt[kidx(hd + t4, pos)] = b;
+            } else if (t4 >= 128) {
+                vc[(size_t)pos * kD + (t4 - 128)] = rv;
             }
         }
     }
@@ -165,29 +176,34 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             }
         }
 #pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) partial[wave][lane][g] = acc[g][0] + acc[g][1];
+        for (int g = 0; g < kMaxGroup; ++g) partial[half][wave][lane][g] = acc[g][0] + acc[g][1];
     }
     __syncthreads();
     // ---- chunk-local softmax pieces: wave g owns head g, lane = position ---------------------
-    // (positions past the context carried stale keys: their scores, whatever they are, are replaced here)
+    // (positions past the context carried stale keys: their scores, whatever they are, are replaced here;
+    //  a dead half has t_k <= j0: every score becomes -inf, m = -inf, l = 0)
     const float scale = 1.0f / sqrtf((float)kD);
     float m_c, l_c;
     {
         const int g = wave, j = j0 + lane;
-        float s = ((partial[0][lane][g] + partial[1][lane][g]) + partial[2][lane][g]) + partial[3][lane][g];
+        float s = ((partial[half][0][lane][g] + partial[half][1][lane][g]) + partial[half][2][lane][g]) + partial[half][3][lane][g];
         s = j < t_k ? s * scale : -INFINITY;
         m_c = awave_max(s);
         const float e = j < t_k ? expf(s - m_c) : 0.0f;
         l_c = awave_sum(e);
         // the new token's value is not in the cache registers: its weight goes aside (enew) and its slot gets 0
-        sc[g][lane & 1][lane >> 1] = j == pos ? 0.0f : e;
+        sc[half][g][lane & 1][lane >> 1] = j == pos ? 0.0f : e;
         if (j == pos) enew[g] = e;
+        if (NH == 2 && lane == 0) {
+            hm[half][g] = m_c;
+            hl[half][g] = l_c;
+        }
     }
     __syncthreads();
     // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
     {
-        const int d = tid & 127, hp = tid >> 7;
+        const int d = t4 & 127, hp = t4 >> 7;
         // Cache slots at or past the new token hold stale bytes; their weights are exact zeros (the new token's own
         // goes through enew), and 0 * finite = 0: the caches must never hold NaN / Inf bit patterns, i.e. be
         // zero-filled before first use (include/bitnet_hip.h) -- then this loop needs no masking at all.
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             const v2f v01 = {vv[i], vv[i + 1]}, v23 = {vv[i + 2], vv[i + 3]};
 #pragma unroll
             for (int g = 0; g < kMaxGroup; ++g) {
-                const float4 w = *reinterpret_cast<const float4 *>(&sc[g][hp][i]);
+                const float4 w = *reinterpret_cast<const float4 *>(&sc[half][g][hp][i]);
                 a[g] = __builtin_elementwise_fma((v2f){w.x, w.y}, v01, a[g]);
                 a[g] = __builtin_elementwise_fma((v2f){w.z, w.w}, v23, a[g]);
             }
@@ -213,14 +229,29 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
             ar[2] += en.z * vnd;
             ar[3] += en.w * vnd;
         }
-        // the two position parities meet through LDS (a buffer of its own: reusing the score partials would cost a barrier)
+        // the position parities (and, NH == 2, the two halves) meet through LDS
 #pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) red[(hp * kMaxGroup + g) * kD + d] = ar[g];
+        for (int g = 0; g < kMaxGroup; ++g) red[half][(hp * kMaxGroup + g) * kD + d] = ar[g];
         __syncthreads();
+        if (NH == 1) {
 #pragma unroll
-        for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = red[g * kD + d] + red[(kMaxGroup + g) * kD + d];
+            for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = red[0][g * kD + d] + red[0][(kMaxGroup + g) * kD + d];
+        } else {
+            // 512 threads: head g = tid >> 7, dim d.  out = e^(m0 - M) o0 + e^(m1 - M) o1 with M = max(m0, m1); a dead
+            // second half has m1 = -inf, l1 = 0, o1 = 0 * stale = 0
+            const int g = tid >> 7;
+            const float m0 = hm[0][g], m1 = hm[1][g], M = fmaxf(m0, m1);
+            const float e0 = __expf(m0 - M), e1 = __expf(m1 - M);
+            const float o0 = red[0][g * kD + d] + red[0][(kMaxGroup + g) * kD + d];
+            const float o1 = red[1][g * kD + d] + red[1][(kMaxGroup + g) * kD + d];
+            rec[2 * kMaxGroup + g * kD + d] = e0 * o0 + e1 * o1;
+            if (d == 0) {
+                rec[2 * g] = M;
+                rec[2 * g + 1] = e0 * hl[0][g] + e1 * hl[1][g];
+            }
+        }
     }
-    if (lane == 0) {
+    if (NH == 1 && lane == 0) {
         rec[2 * wave] = m_c;
         rec[2 * wave + 1] = l_c;
     }
@@ -230,9 +261,9 @@ __global__ __launch_bounds__(256) void k_attn_partial(const float *__restrict__ 
 // c % 8), each merging (m, l, o) online; the 8 partial states meet through LDS.  Threads of a
 // group take 4 dims each (float4: one 512-byte record row per group and step).
 __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_kv, int group,
-                                                      int n_chunks_max, const int *__restrict__ pos_ptr,
+                                                      int n_chunks_max, int chunk_log2, const int *__restrict__ pos_ptr,
                                                       float *__restrict__ out) {
-    asm volatile("" ::"s"(scratch), "s"(n_kv), "s"(group), "s"(n_chunks_max), "s"(out));  // all arguments in one scalar-load round
+    asm volatile("" ::"s"(scratch), "s"(n_kv), "s"(group), "s"(n_chunks_max), "s"(chunk_log2), "s"(out));  // all arguments in one scalar-load round
     const int kvh = blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, d4 = tid & 31, part = tid >> 5;
     __shared__ float sm[8], sl[8];
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
     const float mc0 = rec0[2 * g], lc0 = rec0[2 * g + 1];
     const float4 o0 = *reinterpret_cast<const float4 *>(rec0 + 2 * kMaxGroup + g * kD + 4 * d4);
     const int t_k = *pos_ptr + 1;
-    const int n_chunks = (t_k + kAttnChunk - 1) / kAttnChunk;
+    const int n_chunks = (t_k + (1 << chunk_log2) - 1) >> chunk_log2;  // records of 64 or 128 positions
     const bool has = part < n_chunks;
     float m = has ? mc0 : -INFINITY, l = has ? lc0 : 0.0f;
     float4 a = {has ? o0.x : 0.f, has ? o0.y : 0.f, has ? o0.z : 0.f, has ? o0.w : 0.f};
@@ -302,15 +333,21 @@ size_t attn_scratch_floats(int n_kv, int max_pos) {
 
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine) {
-    if (D != kD || n_heads / n_kv > kMaxGroup) return hipErrorInvalidValue;
-    const int n_chunks = (max_pos + kAttnChunk - 1) / kAttnChunk;
-    hipLaunchKernelGGL(k_attn_partial, dim3(n_kv, n_chunks), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
-                       vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
+                              float *scratch, float *out, hipStream_t stream, bool combine, int halves) {
+    if (D != kD || n_heads / n_kv > kMaxGroup || (halves != 1 && halves != 2)) return hipErrorInvalidValue;
+    const int rec_pos = kAttnChunk * halves;  // positions per record
+    const int n_rec = (max_pos + rec_pos - 1) / rec_pos;
+    if (halves == 2)
+        hipLaunchKernelGGL(k_attn_partial<2>, dim3(n_kv, n_rec), dim3(512), 0, stream, qkv, rope_sin, rope_cos, kcache,
+                           vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
+    else
+        hipLaunchKernelGGL(k_attn_partial<1>, dim3(n_kv, n_rec), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
+                           vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
     // combine == false: the chunk records stay in `scratch` for a consumer that merges them itself
     // (launch_gemv_mfma with GemvFusion::attn_rec)
     if (combine)
-        hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_chunks, pos_ptr, out);
+        hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_rec,
+                           halves == 2 ? 7 : 6, pos_ptr, out);
     return hipGetLastError();
 }
 

@@ -94,7 +94,7 @@ struct MfmaArgs {
     // MERGE: x is the decode attention output, merged here from its chunk records (GemvFusion::attn_rec)
     const float *attn_rec;
     const int *attn_pos;
-    int attn_chunks_max, attn_group_log2;
+    int attn_chunks_max, attn_group_log2, attn_chunk_log2;
     unsigned long long *stamps;  // diagnostic builds only
 };
 
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         if (BS32 == 2) s_h[j] = load_nt16(sbase_h + (size_t)blk * 128);  // 8 halves = 16 B
     }
     int m_chunks = 0;
-    if (MERGE) m_chunks = (*p.attn_pos + 1 + 63) >> 6;  // live chunks, 1..4 (the caller switches to the combine kernel beyond 256 keys)
+    if (MERGE) m_chunks = (*p.attn_pos + (1 << p.attn_chunk_log2)) >> p.attn_chunk_log2;  // live records, 1..4 (the caller switches to the combine kernel beyond that)
     // Every load of this wave is now requested.  Without the fence hipcc moves the activation
     // arithmetic (and its s_waitcnt) up between the weight loads, so that half of the weight stream is
     // only requested once the activations have arrived (~1 us later).
@@ -658,6 +658,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.attn_pos = fu.attn_pos;
     a.attn_chunks_max = fu.attn_chunks_max;
     a.attn_group_log2 = fu.attn_group_log2;
+    a.attn_chunk_log2 = fu.attn_chunk_log2;
     a.stamps = g_mfma_stamps;
     const int tiles_per_wg = nw / a.ksplit;
     const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);

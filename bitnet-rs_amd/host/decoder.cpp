@@ -103,7 +103,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
 }
 
 Decoder::~Decoder() {
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
         if (graph_exec_[i]) hipGraphExecDestroy((hipGraphExec_t)graph_exec_[i]);
         if (graph_[i]) hipGraphDestroy((hipGraph_t)graph_[i]);
     }
@@ -260,14 +260,18 @@ int Decoder::position() {
 }
 
 // One decode step = TransformerModel::forward (T:1557-1597) on one token + logits.
-int Decoder::step_launches(bool with_logits, bool merge_in_oproj) {
+int Decoder::step_launches(bool with_logits, int form) {
     void *s = stream_;
     const size_t H = c_.hidden;
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
     for (auto &L : layers_) {
         // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
         BCHK(bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, s));
-        if (merge_in_oproj) {
+        if (form == 2) {
+            BCHK(bitnet_hip_attention_decode_wide_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
+                                                      (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
+        } else if (form == 1) {
             // short contexts: one attention launch; the o-projection merges the chunk records itself
             BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
                                                          (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, s));
@@ -293,13 +297,23 @@ int Decoder::step_launches(bool with_logits, bool merge_in_oproj) {
     return 0;
 }
 
-int Decoder::ensure_graph(bool with_logits, bool merge_in_oproj) {
-    const int gi = (merge_in_oproj ? 2 : 0) + (with_logits ? 1 : 0);
+// Which attention form a step at `pos` (pos + 1 keys) takes; the host knows every step's position.
+int Decoder::form_at(int pos) const {
+    static const bool merge_env = !(getenv("BITNET_HOST_ATTN_MERGE") && atoi(getenv("BITNET_HOST_ATTN_MERGE")) == 0);
+    static const bool wide_env = !(getenv("BITNET_HOST_ATTN_WIDE") && atoi(getenv("BITNET_HOST_ATTN_WIDE")) == 0);
+    const int keys = pos + 1;
+    if (merge_env && merge_ok_ && keys <= (int)bitnet_hip_attention_merge_max_keys()) return 1;
+    if (wide_env && c_.n_kv_heads * ((keys + 63) / 64) > 256) return 2;  // more 64-position chunks than CUs
+    return 0;
+}
+
+int Decoder::ensure_graph(bool with_logits, int form) {
+    const int gi = 2 * form + (with_logits ? 1 : 0);
     if (graph_exec_[gi]) return 0;
     hipStream_t s = (hipStream_t)stream_;
     hipGraph_t g = nullptr;
     HCHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
-    const int rc = step_launches(with_logits, merge_in_oproj);
+    const int rc = step_launches(with_logits, form);
     const hipError_t e = hipStreamEndCapture(s, &g);
     if (rc != 0) {
         if (g) hipGraphDestroy(g);
@@ -325,19 +339,9 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
     }
     hipStream_t s = (hipStream_t)stream_;
-    // Steps whose context fits 4 attention chunks (position + 1 <= 256) take the form without the combine launch
-    // (BITNET_HOST_ATTN_MERGE=0 keeps the two-kernel attention everywhere); the host knows every step's position.
-    static const bool merge_env = !(getenv("BITNET_HOST_ATTN_MERGE") && atoi(getenv("BITNET_HOST_ATTN_MERGE")) == 0);
-    const bool merge_avail = merge_env && merge_ok_;
-    auto merge_at = [&](int pos) { return merge_avail && pos + 1 <= 256; };
     if (use_graph) {
-        // first call: run one eager step so lazily raised kernel attributes exist before capture
-        if (merge_at(p)) {
-            int rc = ensure_graph(with_logits, true);
-            if (rc) return rc;
-        }
-        if (!merge_at(p + n - 1)) {
-            int rc = ensure_graph(with_logits, false);
+        for (int i = 0; i < n; ++i) {  // every form this run needs (at most three captures)
+            int rc = ensure_graph(with_logits, form_at(p + i));
             if (rc) return rc;
         }
     }
@@ -347,9 +351,9 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
     HCHK(hipEventRecord(e0, s));
     for (int i = 0; i < n; ++i) {
         if (use_graph) {
-            HCHK(hipGraphLaunch((hipGraphExec_t)graph_exec_[(merge_at(p + i) ? 2 : 0) + (with_logits ? 1 : 0)], s));
+            HCHK(hipGraphLaunch((hipGraphExec_t)graph_exec_[2 * form_at(p + i) + (with_logits ? 1 : 0)], s));
         } else {
-            int rc = step_launches(with_logits, merge_at(p + i));
+            int rc = step_launches(with_logits, form_at(p + i));
             if (rc) return rc;
         }
     }

@@ -110,8 +110,11 @@ class Decoder {
 
   private:
     int fail(const char *what);
-    int step_launches(bool with_logits, bool merge_in_oproj);
-    int ensure_graph(bool with_logits, bool merge_in_oproj);
+    // attention form of a step: 0 = two kernels, 64-position chunks; 1 = one kernel + merging o-projection (short
+    // contexts); 2 = two kernels, 128-position chunks (more chunks than CUs)
+    int step_launches(bool with_logits, int form);
+    int ensure_graph(bool with_logits, int form);
+    int form_at(int pos) const;
     bool merge_ok_ = false;  // the o-projection can merge the attention chunk records itself (short contexts)
 
     Config c_;
@@ -137,8 +140,8 @@ class Decoder {
     void *pf_gemm_ws_ = nullptr, *pf_attn_ws_ = nullptr;
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;
-    void *graph_exec_[4] = {nullptr, nullptr, nullptr, nullptr};  // [2 * merge_in_oproj + with_logits]
-    void *graph_[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *graph_exec_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [2 * form + with_logits]
+    void *graph_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int logits_wgs_ = 512;  // two workgroups per CU: whole rounds on the 256 CUs (768 / 1280 workgroups are 15-20 % slower)
 };
 

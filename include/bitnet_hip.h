@@ -273,19 +273,28 @@ int bitnet_hip_attention_decode_dev(const float *qkv_dev, const float *rope_sin_
                                     size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                     const int32_t *pos_dev, float *scratch_dev, float *out_dev,
                                     void *stream);
-/* Short contexts (at most 256 keys = 4 chunks of 64): the attention in ONE launch plus an output projection that
+/* The same operator with workgroups of 512 threads that cover 128 positions each (half as many workgroups and chunk
+ * records).  Slower than bitnet_hip_attention_decode_dev while n_kv_heads * ceil((pos + 1) / 64) fits the 256 CUs
+ * (+1.5 us per layer at 0.4k..2.5k keys), faster beyond (4k keys, 5 KV heads: 320 -> 160 workgroups, 11.9 -> 10.9 us). */
+int bitnet_hip_attention_decode_wide_dev(const float *qkv_dev, const float *rope_sin_dev,
+                                         const float *rope_cos_dev, float *kcache_dev, float *vcache_dev,
+                                         size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                         const int32_t *pos_dev, float *scratch_dev, float *out_dev,
+                                         void *stream);
+/* Short contexts (at most bitnet_hip_attention_merge_max_keys() keys = 4 records of 64 positions): the attention in ONE launch plus an output projection that
  * merges the chunk results itself.  bitnet_hip_attention_decode_partial_dev = the first of the two kernels of
  * bitnet_hip_attention_decode_dev (RoPE, KV append, per-chunk softmax pieces into scratch_dev; same arguments,
  * no out_dev); bitnet_hip_gemv_attn_merge_dev(w, scratch, ...) = bitnet_hip_gemv_fused_dev(w, attention output,
  * y, m = 1, no LayerNorm, residual) with the attention output assembled from those records on the fly (every
  * workgroup of the projection reads every live record, n_chunks x 10 KB -- which is why this is for short
  * contexts only; the caller falls back to bitnet_hip_attention_decode_dev + bitnet_hip_gemv_fused_dev once
- * *pos_dev + 1 exceeds 256).  w: cols == n_heads * 128; query group 1, 2 or 4.  scratch_dev must be zero-filled
+ * *pos_dev + 1 exceeds that).  w: cols == n_heads * 128; query group 1, 2 or 4.  scratch_dev must be zero-filled
  * before its first use (records of chunks past the context are read and given zero weight). */
 int bitnet_hip_attention_decode_partial_dev(const float *qkv_dev, const float *rope_sin_dev, const float *rope_cos_dev,
                                             float *kcache_dev, float *vcache_dev, size_t n_heads, size_t n_kv_heads,
                                             size_t head_dim, size_t max_pos, const int32_t *pos_dev, float *scratch_dev,
                                             void *stream);
+size_t bitnet_hip_attention_merge_max_keys(void); /* largest *pos_dev + 1 the merging projection takes (4 records) */
 int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
                                    size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
                                    const float *residual_dev, void *stream);

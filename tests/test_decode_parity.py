@@ -217,7 +217,8 @@ def test_decode_across_chunk_boundaries_teacher_forced(hip, pkg, oracle, synth):
     (512, [0, 63, 64, 200], 4, 2),      # query group of 2
     (512, [5, 64, 191], 3, 3),          # no grouping
     (8192, [0, 100, 3071, 3072, 5000, 8100], 8, 2)])
-def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions, n_heads, n_kv):
+@pytest.mark.parametrize("wide", [False, True])
+def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions, n_heads, n_kv, wide):
     """One-token attention (RoPE + append + GQA softmax) at many context lengths against a f64 numpy
     reference; max_pos 8192 takes the long-context form (several 64-position chunks per workgroup,
     merged online)."""
@@ -242,7 +243,8 @@ def test_attention_decode_op_vs_f64(hip, oracle, torch_, max_pos, positions, n_h
         kcd, vcd = dev(tiled(kc_in)), dev(vc_in)
         out = torch_.full((n_heads * D,), float("nan"), device="cuda")
         pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
-        hip.attention_decode_dev(dev(qkv), sin_d, cos_d, kcd, vcd, n_heads, n_kv, D, max_pos, pos_d, scratch, out)
+        # wide: workgroups of 512 threads over 128 positions (bitnet_hip_attention_decode_wide_dev), same value
+        (hip.attention_decode_wide_dev if wide else hip.attention_decode_dev)(dev(qkv), sin_d, cos_d, kcd, vcd, n_heads, n_kv, D, max_pos, pos_d, scratch, out)
         torch_.cuda.synchronize()
         got = out.cpu().numpy().reshape(n_heads, D)
         rot = lambda x: np.concatenate([x[..., :64] * cos[pos] - x[..., 64:] * sin[pos], x[..., :64] * sin[pos] + x[..., 64:] * cos[pos]], axis=-1)
