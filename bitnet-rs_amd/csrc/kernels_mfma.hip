@@ -288,6 +288,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         // dead records hold zeros or an earlier token's values (finite): only their m is masked below
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
+            if (b0 + j >= b1) continue;  // wave-uniform: a K range shorter than RING blocks (10 blocks over 8 waves) skips the slot
             const uint32_t kf = umin32(xo0 + 1024u * j, last_vec) >> 2;  // first of this lane's 4 columns
             const uint32_t h = kf >> 7, d = kf & 127u, kvh = h >> p.attn_group_log2, g = h & ((1u << p.attn_group_log2) - 1u);
             mrec[j] = p.attn_rec + (size_t)kvh * p.attn_chunks_max * kAttnRecFloats + 2 * g;
@@ -337,6 +338,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
         // softmax merge of the chunk records: out = sum_c e^(m_c - M) o_c / sum_c e^(m_c - M) l_c  (k_attn_combine's value)
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
+            if (b0 + j >= b1) {  // skipped slot: zero digits
+                xr[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                continue;
+            }
             float M = -INFINITY;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
