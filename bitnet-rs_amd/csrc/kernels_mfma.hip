@@ -247,7 +247,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     const int n_tiles = (p.rows + 15) >> 4;
     int tile = blockIdx.x * tiles_per_wg + (wave >> p.ks_log2);
     tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
-    const int kpart = wave & (p.ksplit - 1);
+    // K split 8 over a block count that 8 does not divide gives ranges of n and n + 1 blocks, the longer ones at
+    // kparts 3 and 7 -- waves 3 and 7 share SIMD 3 (wave i runs on SIMD i % 4).  Waves 4..7 therefore take
+    // kparts 7..4: every SIMD gets at most one long range.  The partial sums are stored by kpart, so the value
+    // (and its summation order) does not change.
+    int kpart = wave & (p.ksplit - 1);
+    if (p.ks_log2 == 3 && wave >= 4) kpart = 11 - wave;
     const int b0 = (kpart * p.nblk) >> p.ks_log2, b1 = ((kpart + 1) * p.nblk) >> p.ks_log2;
     const int nvec = p.cols >> 2;  // cols % 4 == 0
 
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
+        if (j > 0 && b0 + j >= b1) continue;  // wave-uniform: a slot past this wave's range would only add exact zeros
         const uint32_t wd[4] = {wt[j].x, wt[j].y, wt[j].z, wt[j].w};
         if (BS32) {
             // 32-element blocks: column c = 4*kg + d carries digit d of k-group kg only (B is
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
     }
     if (r16 == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[wave * 16 + 4 * g + j] = f[j];
+        for (int j = 0; j < 4; ++j) part[(((wave >> p.ks_log2) << p.ks_log2) + kpart) * 16 + 4 * g + j] = f[j];
     }
     __syncthreads();
     // only the storing threads (the first tiles_per_wg * 16, i.e. the first wave or two) go on: the other
