@@ -9,7 +9,7 @@
 // and v_mfma_i32_16x16x64_i8 does every multiply-add.
 //
 // Exactness: activations are converted once per launch to 30-bit fixed point with
-// one power-of-two scale per activation row (q = floor(x * 2^(29-E) + 1/2), |q| <= 2^30)
+// one power-of-two scale per wave's K range (q = floor(x * 2^(29-E) + 1/2), |q| <= 2^30)
 // and split into four balanced base-256 digits d0..d3 in [-128,127].  The four
 // digit planes are four B-matrix columns of the MFMA, so
 //     sum_k w[r,k] * x[k]  =  2^(E-29) * sum_d 256^d * (sum_k w[r,k] * d_d[k])
@@ -26,10 +26,10 @@
 // comes out in natural K order and the activation digit planes are stored in
 // natural order too.
 //
-// Launch latency: every launch starts with a cold instruction cache on this chip
-// (measured: ~30-90 ns per 64-byte line of straight-line code), so the kernel is
-// written for a small instruction footprint: a 4-deep register ring of weight tiles
-// instead of a fully unrolled K loop, runtime flags instead of template variants.
+// Launch latency decides this kernel, not bandwidth ("Latency work"): one round of workgroups
+// (<= 256), every load of a wave requested up front (the whole K range of a wave lives in registers: RING
+// 1-KiB tiles), the wave index in an SGPR so that index math runs on the scalar unit, ~650 VALU instructions
+// per wave between "activations arrived" and "MFMA loop done", long K ranges spread over the SIMDs.
 #include <cstdlib>
 #include <unordered_set>
 
