@@ -115,3 +115,23 @@ def test_overflowing_dimensions_are_refused_before_any_multiplication(lib):
     lib.bitnet_hip_matmul_i2s.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.c_size_t] * 3
     rc = lib.bitnet_hip_matmul_i2s(buf, 0, buf, 0, fl, 0, 1 << 32, 1 << 32, 0)
     assert rc != 0 and b"too large" in lib.bitnet_hip_get_last_error()
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu(lib):
+    import ctypes as C
+
+    c = C.CDLL(lib.path)
+    c.bitnet_hip_get_last_error.restype = C.c_char_p
+    c.bitnet_hip_attention_merge_max_keys.restype = C.c_size_t
+    assert c.bitnet_hip_attention_merge_max_keys() == 256
+    c.bitnet_hip_gemv_attn_merge_dev.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert c.bitnet_hip_gemv_attn_merge_dev(12345, None, 8, 2, 512, None, None, None, None) != 0
+    assert b"unknown weights handle" in c.bitnet_hip_get_last_error()
+    c.bitnet_hip_hbm_read_ceiling.argtypes = [C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    best, mean = C.c_double(), C.c_double()
+    assert c.bitnet_hip_hbm_read_ceiling(16, 1, C.byref(best), C.byref(mean), None) != 0  # below 1 MiB
+    assert b"hbm_read_ceiling" in c.bitnet_hip_get_last_error()
+    assert c.bitnet_hip_hbm_read_ceiling(1 << 30, 1, None, None, None) != 0
+    c.bitnet_hip_attention_decode_partial_dev.argtypes = [C.c_void_p] * 5 + [C.c_size_t] * 4 + [C.c_void_p] * 3
+    assert c.bitnet_hip_attention_decode_partial_dev(None, None, None, None, None, 8, 2, 128, 512, None, None, None) != 0
+    assert b"Null pointer" in c.bitnet_hip_get_last_error()
