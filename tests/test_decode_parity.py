@@ -348,3 +348,28 @@ def test_oproj_merging_the_attention_records_equals_combine_then_project(hip, pk
         assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, np.max(np.abs(a))), (n_heads, n_kv, pos, np.max(np.abs(a - b)))
         assert torch_.equal(k1, k2) and torch_.equal(v1, v2)  # the same cache append
     hip.weights_free(w)
+
+
+def test_decode_is_bit_reproducible_run_to_run(hip, pkg, synth):
+    """No atomics, fixed summation orders: the same token sequence gives bit-identical logits on every run and
+    whether the steps are replayed from the step graphs or launched one by one."""
+    cfg = synth.ModelConfig(**LONG)
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w)
+    dec.set_globals(glob)
+    prompt = synth.prompt(12, cfg.vocab)
+    runs = []
+    for use_graph in (True, True, False):
+        dec.reset()
+        dec.feed(prompt)
+        logits = []
+        for _ in range(70):  # crosses the 64-position chunk boundary
+            dec.run(1, with_logits=True, use_graph=use_graph)
+            logits.append(dec.last_logits().copy())
+        runs.append((np.stack(logits), list(dec.history(71))))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    assert np.array_equal(runs[0][0], runs[2][0]) and runs[0][1] == runs[2][1]
+    dec.close()
