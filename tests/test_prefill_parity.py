@@ -266,3 +266,39 @@ def test_prefill_attention_is_causal_and_block_independent(hip, oracle, torch_):
                                       wsb2, out)
     torch_.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), base[rows])
+
+
+MANYKV = dict(hidden=1024, n_layers=2, n_heads=8, n_kv_heads=8, head_dim=128, ffn=1024, vocab=2048, max_pos=2176, eps=1e-5, rope_theta=10000.0)
+
+
+def test_decode_switches_to_the_wide_attention_form(pkg, oracle, synth):
+    """With 8 KV heads the 64-position chunks outnumber the 256 CUs beyond 2048 keys, where the decoder changes to the
+    128-position attention workgroups (a third step graph): prefill 2040 tokens, then decode across the switch, every
+    step against the oracle (teacher-forced)."""
+    cfg = synth.ModelConfig(**MANYKV)
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    n_prompt, n_new = 2040, 16
+    om = oracle.OracleModel(cfg, layers, glob, n_threads=8)
+    seq = list(synth.prompt(n_prompt, cfg.vocab))
+    o_logits = []
+    for p in range(n_prompt + n_new - 1):
+        _, logits, _ = om.step(seq[p], want_logits=p >= n_prompt - 1)
+        if p >= n_prompt - 1:
+            o_logits.append(logits)
+            seq.append(oracle.argmax(logits))
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w)
+    dec.set_globals(glob)
+    dec.reset()
+    dec.feed(seq)  # every token forced to the oracle's
+    dec.prefill(n_prompt, with_logits=True, digits=4)
+    assert cosine(dec.last_logits(), o_logits[0]) >= 0.9999
+    for i in range(1, n_new):
+        dec.run(1, with_logits=True, use_graph=True)  # keys 2041 .. 2055: crosses 2048
+        c = cosine(dec.last_logits(), o_logits[i])
+        assert c >= 0.9999, (i, c)
+    assert dec.position() == n_prompt + n_new - 1
+    dec.close()
+    om.close()
