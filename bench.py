@@ -138,8 +138,30 @@ def cpu_baseline(cfg, synth):
         **extra,
         "sample": f"oracle/ restatement of gemv_qk256_{impl} on 1 layer (7 GEMVs, 17.4 MB codes), median of 5 after 1 warm-up = "
         f"{t_layer * 1e3:.1f} ms, x{cfg.n_layers} layers + logits GEMV ({t_logits * 1e3:.0f} ms, numpy f32 on 1/16 of the vocab x16); "
-        "reference published 0.5126 tok/s on a 9950X3D (docs/baselines/perf/phase2_timing_i2s.md)",
+        "reference published 0.5126 tok/s on a 9950X3D (docs/baselines/perf/phase2_timing_i2s.md). Storage formats differ by design: the reference's "
+        "live CPU decode path exists for QK256 only (2 bits/weight, no scales), the GPU line above streams BitNet32-F16 (2.5 bits/weight) unless --workload c3",
     }
+
+
+def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
+    """Logits of the fast (fused, hipGraph) step vs Decoder::run_reference (unfused, BITNET_HIP_KERNEL_EXACT = the scalar
+    reference's summation order) after the same n_tokens forced tokens.  Not timed."""
+    toks = synth.prompt(n_tokens, cfg.vocab)
+    out = []
+    for ref in (False, True):
+        dec.reset()
+        dec.feed(toks)
+        if ref:
+            dec.run_reference(n_tokens - 1, with_logits=False)
+            dec.run_reference(1, with_logits=True)
+        else:
+            dec.run(n_tokens - 1, with_logits=False, use_graph=True)
+            dec.run(1, with_logits=True, use_graph=True)
+        out.append((dec.last_logits().astype(np.float64), int(dec.history(n_tokens + 1)[n_tokens])))
+    (a, ta), (b, tb) = out
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+    return {"logits_cosine_fast_vs_exact_kernels": round(cos, 8), "max_abs_diff_over_max_abs": float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300)),
+            "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
 def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
@@ -202,6 +224,22 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU) BEFORE anything here
+    # touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Under torchrun WORLD_SIZE must agree.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    if int(env_world or "1") != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world or 1}: launch one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus})")
+
     import torch
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback path)"
@@ -257,7 +295,7 @@ def main():
     achieved = abytes / us / 1e3  # GB/s
     roofline = {
         "bound": "hbm",
-        "kernel": "k_gemv_mfma (fused LayerNorm -> gate|up GEMV -> silu*mul)" if True else "",
+        "kernel": "k_gemv_mfma (fused LayerNorm -> gate|up GEMV -> silu*mul)",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -275,6 +313,9 @@ def main():
     for kind, name in enumerate(("qkv", "attention", "o_proj", "gate_up", "down", "logits")):
         k_us, k_bytes = dec.probe_kernel(kind, 20)
         kernel_table[name] = {"us_per_launch": round(k_us, 2), "GBps": round(k_bytes / k_us / 1e3, 1)}
+    # outside the timed region: the fast step against the UNFUSED step on the reference-order (bit-exact) kernels, same
+    # weights, same short prompt, at the full model size -- a wrong fast kernel cannot hide behind a plausible rate
+    check = exact_step_check(dec, synth, cfg)
     # whole-step view of the same metric: all I2_S matrices of one token / step time
     wb = dec.weight_bytes()
     i2s_gbs = wb / (elapsed / args.steps) / 1e9
@@ -294,10 +335,10 @@ def main():
             "dtype": "i8 MFMA on exact 30-bit fixed-point activations, f32 accumulate / f32 elsewhere (f16 embedding table)",
             "data": "synthetic",
             "config": {
-                "workload": "bitnet-b1.58-2B-4T I2_S BitNet32 (ternary, 32-elem block scales), 1xMI355X, batch=1 decode, 128-token prompt"
+                "workload": f"bitnet-b1.58-2B-4T I2_S BitNet32-F16 (ternary, one f16 scale per 32 weights), {n_gpus}xMI355X, batch=1 decode, {PROMPT_LEN}-token prompt"
                 if args.workload == "c2"
-                else "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt" if args.workload == "c3"
-                else f"bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, {PROMPT_LEN}-token prefill + decode",
+                else f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {n_gpus}xMI355X, batch=1 decode, {PROMPT_LEN}-token prompt" if args.workload == "c3"
+                else f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {n_gpus}xMI355X, {PROMPT_LEN}-token prefill + decode",
                 "layers": cfg.n_layers,
                 "prompt_len": PROMPT_LEN,
                 "kv_len_during_timing": [PROMPT_LEN + 1 + args.warmup, PROMPT_LEN + 1 + args.warmup + args.steps],
@@ -311,6 +352,8 @@ def main():
             "roofline": roofline,
             "per_kernel": kernel_table,
             "last_tokens": [int(t) for t in tokens[-4:]],
+            "distinct_tokens_in_timed_steps": int(len(set(int(t) for t in tokens[-args.steps:]))),
+            "exact_step_check": check,
         }
         if prefill_ms is not None:
             flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers

@@ -116,6 +116,9 @@ class HipLib:
         L.bitnet_hip_weights_info.argtypes = [C.c_uint64, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]
         L.bitnet_hip_gemv_dev.argtypes = [C.c_uint64, _vp, _vp, _vp]
         L.bitnet_hip_matmul_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp]
+        L.bitnet_hip_matmul_kernel_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, C.c_int, _vp]
+        L.bitnet_hip_add_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
+        L.bitnet_hip_silu_mul_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp]
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
@@ -328,6 +331,15 @@ class HipLib:
     def matmul_dev(self, h: int, x, y, m: int, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_matmul_dev(h, _ptr(x), _ptr(y), m, _vp(stream)))
 
+    def matmul_kernel_dev(self, h: int, x, y, m: int, kernel: int, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_matmul_kernel_dev(h, _ptr(x), _ptr(y), m, kernel, _vp(stream)))
+
+    def add_dev(self, a, b, out, n: int, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_add_dev(_ptr(a), _ptr(b), _ptr(out), n, _vp(stream)))
+
+    def silu_mul_dev(self, gate, up, out, n: int, tile: int = 0, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_silu_mul_dev(_ptr(gate), _ptr(up), _ptr(out), n, tile, _vp(stream)))
+
     def weights_concat(self, parts, interleave16: bool = False) -> int:
         arr = (C.c_uint64 * len(parts))(*parts)
         h = C.c_uint64(0)
@@ -519,6 +531,7 @@ class HostDecoder:
         L.bitnet_host_reset.argtypes = [C.c_void_p]
         L.bitnet_host_feed.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.bitnet_host_run_reference.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bitnet_host_position.argtypes = [C.c_void_p]
         L.bitnet_host_history.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_last_logits.argtypes = [C.c_void_p, _f32p]
@@ -530,6 +543,8 @@ class HostDecoder:
         self.cfg = cfg
         hc = HostConfig(**{k: (float(v) if k in ("eps", "rope_theta") else int(v)) for k, v in cfg.asdict().items()})
         self.h = L.bitnet_host_create(C.byref(hc))
+        if not self.h:
+            raise BitNetHipError(ERR_GPU, "bitnet_host_create failed (allocation)")
         err = self.error()
         if err:
             raise BitNetHipError(ERR_GPU, err)
@@ -579,6 +594,10 @@ class HostDecoder:
         ms = C.c_float(0)
         self._check(self.c.bitnet_host_run(self.h, n, int(with_logits), int(use_graph), C.byref(ms)))
         return ms.value
+
+    def run_reference(self, n: int, with_logits: bool = True) -> None:
+        """n UNFUSED steps on the bit-exact reference-order kernels (the checker of the fast step; slow)."""
+        self._check(self.c.bitnet_host_run_reference(self.h, n, int(with_logits)))
 
     def prefill(self, n: int, with_logits: bool = True, digits: int = 4) -> float:
         self.c.bitnet_host_prefill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]

@@ -3,8 +3,10 @@
 // Argument validation mirrors the reference function each symbol replaces (cited in
 // the header); kernels live in kernels_*.hip.  No CPU fallback exists here: every
 // compute path needs a HIP device.
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -17,12 +19,17 @@ thread_local std::string g_last_error;
 
 namespace {
 
+// The provider trait is Send + Sync (K/lib.rs:39) and a KernelManager is shared through an Arc per layer
+// (crates/bitnet-inference/src/layers/quantized_linear.rs:165,208): every entry point may run concurrently with every
+// other one, weights_free included.  Handles therefore map to REFERENCE-COUNTED matrices: a call holds its own
+// reference for its whole duration, weights_free only drops the table's, and the device memory goes with the last one.
 std::mutex g_mu;
 bool g_inited = false;
 int g_device = 0;
-int g_kernel = BITNET_HIP_KERNEL_AUTO;
+std::atomic<int> g_kernel{BITNET_HIP_KERNEL_AUTO};  // default kernel of the calls that do not name one
 uint64_t g_next_handle = 1;
-std::unordered_map<uint64_t, Weights *> g_weights;
+using WeightsRef = std::shared_ptr<Weights>;
+std::unordered_map<uint64_t, WeightsRef> g_weights;
 
 void free_weights(Weights *w) {
     if (!w) return;
@@ -35,10 +42,10 @@ void free_weights(Weights *w) {
     delete w;
 }
 
-Weights *lookup(bitnet_hip_weights_t h) {
+WeightsRef lookup(bitnet_hip_weights_t h) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_weights.find(h);
-    return it == g_weights.end() ? nullptr : it->second;
+    return it == g_weights.end() ? WeightsRef() : it->second;
 }
 
 int ensure_init() {
@@ -50,9 +57,10 @@ int ensure_init() {
 }
 
 int register_weights(Weights *w, bitnet_hip_weights_t *out) {
+    WeightsRef ref(w, free_weights);
     std::lock_guard<std::mutex> lk(g_mu);
     uint64_t h = g_next_handle++;
-    g_weights[h] = w;
+    g_weights[h] = std::move(ref);
     *out = h;
     return BITNET_HIP_OK;
 }
@@ -84,8 +92,8 @@ bool dims_sane(size_t a, size_t b, size_t c = 1) {
     if (!dims_sane(__VA_ARGS__))                                                                         \
     return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions too large for this library (%s)", #__VA_ARGS__)
 
-int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvFusion &fu, hipStream_t stream) {
-    int kernel = g_kernel;
+int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvFusion &fu, hipStream_t stream, int kernel = -1) {
+    if (kernel < 0) kernel = g_kernel.load(std::memory_order_relaxed);
     if (kernel == BITNET_HIP_KERNEL_AUTO) kernel = BITNET_HIP_KERNEL_MFMA;
     if ((kernel == BITNET_HIP_KERNEL_MFMA || kernel == BITNET_HIP_KERNEL_MFMA_TILED) && !mfma_supported(w))
         kernel = BITNET_HIP_KERNEL_VALU;
@@ -154,8 +162,7 @@ int bitnet_hip_init(int device) {
 void bitnet_hip_cleanup(void) {
     try {
         std::lock_guard<std::mutex> lk(g_mu);
-        for (auto &kv : g_weights) free_weights(kv.second);
-        g_weights.clear();
+        g_weights.clear();  // matrices still used by a running call go with that call's reference
         g_inited = false;
         g_last_error.clear();
     } catch (...) {
@@ -198,11 +205,11 @@ int bitnet_hip_get_device_info(int device, bitnet_hip_device_info *out) {
 int bitnet_hip_set_kernel(int kernel) {
     if (kernel < BITNET_HIP_KERNEL_AUTO || kernel > BITNET_HIP_KERNEL_MFMA_TILED)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
-    g_kernel = kernel;
+    g_kernel.store(kernel, std::memory_order_relaxed);
     return BITNET_HIP_OK;
 }
 
-int bitnet_hip_get_kernel(void) { return g_kernel; }
+int bitnet_hip_get_kernel(void) { return g_kernel.load(std::memory_order_relaxed); }
 
 /* ---------------------------------------------------------------- handles */
 
@@ -356,23 +363,23 @@ int bitnet_hip_weights_upload_inline_f16(const uint8_t *blocks, size_t len, size
 
 int bitnet_hip_weights_free(bitnet_hip_weights_t h) {
     BH_GUARD_BEGIN
-    Weights *w = nullptr;
+    WeightsRef w;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_weights.find(h);
         if (it == g_weights.end())
             return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu",
                              (unsigned long long)h);
-        w = it->second;
+        w = std::move(it->second);
         g_weights.erase(it);
     }
-    free_weights(w);
+    w.reset();  // the last reference frees the device memory: here, or when a concurrent call on this handle returns
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
 
 int bitnet_hip_weights_info(bitnet_hip_weights_t h, size_t *rows, size_t *cols, size_t *algorithmic_bytes) {
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (rows) *rows = w->rows;
     if (cols) *cols = w->cols;
@@ -384,27 +391,41 @@ int bitnet_hip_gemv_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev
     return bitnet_hip_matmul_dev(h, x_dev, y_dev, 1, stream);
 }
 
-int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m, void *stream) {
+static int matmul_dev_kernel(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m, int kernel, void *stream) {
     BH_GUARD_BEGIN
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_dev");
     if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
-    const bool mfma_ok = g_kernel == BITNET_HIP_KERNEL_AUTO || g_kernel == BITNET_HIP_KERNEL_MFMA || g_kernel == BITNET_HIP_KERNEL_MFMA_TILED;
+    if (kernel < 0) kernel = g_kernel.load(std::memory_order_relaxed);
+    if (kernel < BITNET_HIP_KERNEL_AUTO || kernel > BITNET_HIP_KERNEL_MFMA_TILED)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+    const bool mfma_ok = kernel == BITNET_HIP_KERNEL_AUTO || kernel == BITNET_HIP_KERNEL_MFMA || kernel == BITNET_HIP_KERNEL_MFMA_TILED;
     if (m >= 16 && mfma_ok && gemm_supported(*w)) {
-        // many rows: one tiled matmul instead of m GEMV launches; the digit-plane workspace lives
-        // for this call only (callers that care pass their own to bitnet_hip_matmul_fused_dev)
+        // many rows: one tiled matmul instead of m GEMV launches.  The digit-plane workspace is allocated and
+        // released IN STREAM ORDER (no host synchronisation, nothing that outlives the call on the host side);
+        // callers that replay the call from a hipGraph pass their own workspace to bitnet_hip_matmul_fused_dev.
         const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
         void *ws = nullptr;
-        if (hipMalloc(&ws, wsb) != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed for the matmul workspace (%zu bytes)", wsb);
+        if (hipMallocAsync(&ws, wsb, (hipStream_t)stream) != hipSuccess)
+            return set_error(BITNET_HIP_ERR_GPU, "hipMallocAsync failed for the matmul workspace (%zu bytes)", wsb);
         hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, GemvFusion(), 4, ws, wsb, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(ws);
+        const hipError_t ef = hipFreeAsync(ws, (hipStream_t)stream);
+        if (e == hipSuccess) e = ef;
         if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
         return BITNET_HIP_OK;
     }
-    return run_gemv(*w, x_dev, y_dev, m, GemvFusion(), (hipStream_t)stream);
+    return run_gemv(*w, x_dev, y_dev, m, GemvFusion(), (hipStream_t)stream, kernel);
     BH_GUARD_END
+}
+
+int bitnet_hip_matmul_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m, void *stream) {
+    return matmul_dev_kernel(h, x_dev, y_dev, m, -1, stream);
+}
+
+int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m, int kernel, void *stream) {
+    if (kernel < 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+    return matmul_dev_kernel(h, x_dev, y_dev, m, kernel, stream);
 }
 
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits) {
@@ -415,7 +436,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags, int digits,
                                 void *workspace_dev, size_t workspace_bytes, void *stream) {
     BH_GUARD_BEGIN
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_fused_dev");
     if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
@@ -442,7 +463,7 @@ int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float 
                               const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags,
                               void *stream) {
     BH_GUARD_BEGIN
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!x_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_fused_dev");
     if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
@@ -460,7 +481,7 @@ int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float 
 
 int bitnet_hip_weights_bind_ln(bitnet_hip_weights_t h, const float *ln_gamma_dev, void *stream) {
     BH_GUARD_BEGIN
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!ln_gamma_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_bind_ln");
     if (!mfma_supported(*w)) return BITNET_HIP_OK;  // other kernels keep the prologue form
@@ -481,10 +502,10 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     BH_GUARD_BEGIN
     if (!parts || !out || n_parts == 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to weights_concat");
-    std::vector<Weights *> ws;
+    std::vector<WeightsRef> ws;
     size_t rows = 0;
     for (size_t i = 0; i < n_parts; ++i) {
-        Weights *w = lookup(parts[i]);
+        const WeightsRef w = lookup(parts[i]);
         if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)parts[i]);
         if (i > 0 && (w->cols != ws[0]->cols || w->row_stride_bytes != ws[0]->row_stride_bytes || w->lut != ws[0]->lut ||
                       w->block_size != ws[0]->block_size || (w->scales == nullptr) != (ws[0]->scales == nullptr)))
@@ -503,11 +524,11 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->scale_tiles_h = nullptr;
     f->ln_g = nullptr;
     f->ln_gamma_bound = nullptr;
-    for (Weights *w : ws) f->scales_f16 = f->scales_f16 && w->scales_f16;
+    for (const WeightsRef &w : ws) f->scales_f16 = f->scales_f16 && w->scales_f16;
     f->rows = rows;
     f->paired = interleave16 != 0;
     f->algorithmic_bytes = 0;
-    for (Weights *w : ws) {
+    for (const WeightsRef &w : ws) {
         f->algorithmic_bytes += w->algorithmic_bytes;
         if (w->scales_f16 && !f->scales_f16) f->algorithmic_bytes += 2 * w->rows * w->nblk;  // stored as f32 in the fused matrix
     }
@@ -525,7 +546,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
         }
     } else if (ok) {
         size_t r0 = 0;
-        for (Weights *w : ws) {
+        for (const WeightsRef &w : ws) {
             ok = ok && hipMemcpy(f->codes + r0 * stride, w->codes, w->rows * stride, hipMemcpyDeviceToDevice) == hipSuccess;
             if (ok && f->scales)
                 ok = hipMemcpy((uint8_t *)f->scales + r0 * sstride, w->scales, w->rows * sstride, hipMemcpyDeviceToDevice) == hipSuccess;
@@ -580,6 +601,25 @@ int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream) {
     BH_GUARD_BEGIN
     if (!pos_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to advance_pos_dev");
     BH_HIP_TRY(launch_advance_pos(pos_dev, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_add_dev(const float *a_dev, const float *b_dev, float *out_dev, size_t n, void *stream) {
+    BH_GUARD_BEGIN
+    if (!a_dev || !b_dev || !out_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to add_dev");
+    if (n == 0) return BITNET_HIP_OK;
+    BH_HIP_TRY(launch_add(a_dev, b_dev, out_dev, n, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_silu_mul_dev(const float *gate_dev, const float *up_dev, float *out_dev, size_t n, size_t tile, void *stream) {
+    BH_GUARD_BEGIN
+    if (!gate_dev || !up_dev || !out_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to silu_mul_dev");
+    if (n == 0) return BITNET_HIP_OK;
+    if (tile != 0 && n % tile != 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "silu_mul: n %zu is not a multiple of the tile %zu", n, tile);
+    BH_HIP_TRY(launch_silu_mul(gate_dev, up_dev, out_dev, n, tile, (hipStream_t)stream));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
@@ -650,7 +690,7 @@ size_t bitnet_hip_attention_merge_max_keys(void) { return (size_t)4 * 64; }
 int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
                                    size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *stream) {
     BH_GUARD_BEGIN
-    Weights *w = lookup(h);
+    const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
     if (!attn_scratch_dev || !pos_dev || !y_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_dev");
     const size_t group = n_kv_heads ? n_heads / n_kv_heads : 0;

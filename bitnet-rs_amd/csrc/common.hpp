@@ -117,6 +117,10 @@ hipError_t launch_dequant_i2s(const uint8_t *bytes, size_t rows, size_t cols, si
 hipError_t launch_embed_f16(const void *table, const int *tokens, const int *offset_ptr, int n, int hidden,
                             int vocab, float *out, hipStream_t stream);
 hipError_t launch_advance_pos(int *pos_ptr, hipStream_t stream);
+hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+// out[i] = silu(gate[.]) * up[.]; tile == 0: gate[i], up[i]; tile > 0: both live in ONE buffer of alternating
+// tile-row groups (gate tile, up tile, ...), gate = the buffer, up = gate + tile (weights_concat interleave16)
+hipError_t launch_silu_mul(const float *gate, const float *up, float *out, size_t n, size_t tile, hipStream_t stream);
 hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int rows, int hidden, float eps,
                             bool rms, hipStream_t stream);
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,

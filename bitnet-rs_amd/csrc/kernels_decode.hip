@@ -236,7 +236,7 @@ hipError_t launch_logits_f16(const void *table, const float *x, const float *gam
                              float *logits, float *best_val, int *best_idx, int n_wg, hipStream_t stream) {
     if (hidden % 512 != 0 || hidden > 512 * kLogitChunks) return hipErrorInvalidValue;
     void (*kfn)(const _Float16 *, const float *, const float *, float, int, int, float *, float *, int *) = nullptr;
-    const int rows = getenv("BITNET_HIP_LOGIT_ROWS") ? atoi(getenv("BITNET_HIP_LOGIT_ROWS")) : 3;  // tuning knob
+    static const int rows = getenv("BITNET_HIP_LOGIT_ROWS") ? atoi(getenv("BITNET_HIP_LOGIT_ROWS")) : 3;  // tuning knob, read once
     switch (hidden / 512) {
         case 1: kfn = k_logits_f16<1, 4>; break;
         case 2: kfn = k_logits_f16<2, 4>; break;
@@ -258,6 +258,28 @@ hipError_t launch_argmax_final(const float *best_val, const int *best_idx, int n
 }
 
 // Advance the position without sampling (prompt positions whose logits nobody reads).
+// ---- elementwise steps of the UNFUSED decode step (the reference's own op order: T:1073 residual add,
+//      T:765-781 silu(gate) * up); the fast path fuses both into the GEMV epilogues -----------------------
+__global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+    return hipGetLastError();
+}
+__global__ void k_silu_mul(const float *__restrict__ gate, const float *__restrict__ up, float *__restrict__ out, size_t n, size_t tile) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t j = tile ? (i / tile) * 2 * tile + i % tile : i;
+    const float g = gate[j], u = up[j];
+    out[i] = g / (1.0f + expf(-g)) * u;
+}
+hipError_t launch_silu_mul(const float *gate, const float *up, float *out, size_t n, size_t tile, hipStream_t stream) {
+    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gate, up, out, n, tile);
+    return hipGetLastError();
+}
+
 __global__ void k_advance_pos(int *pos_ptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *pos_ptr = *pos_ptr + 1;
 }

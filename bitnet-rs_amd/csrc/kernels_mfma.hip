@@ -31,6 +31,7 @@
 // 1-KiB tiles), the wave index in an SGPR so that index math runs on the scalar unit, ~650 VALU instructions
 // per wave between "activations arrived" and "MFMA loop done", long K ranges spread over the SIMDs.
 #include <cstdlib>
+#include <mutex>
 #include <unordered_set>
 
 #include "common.hpp"
@@ -653,7 +654,8 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.lut = w.lut;
     // many row tiles: 16-wave workgroups, one per CU, so no second workgroup's activation loads
     // queue behind the first one's weight stream in the CU's memory pipeline
-    const int nw = (getenv("BITNET_HIP_NW16") && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
+    static const bool nw16_env = getenv("BITNET_HIP_NW16") != nullptr;  // tuning knob, read once (never on the launch path)
+    const int nw = (nw16_env && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
     a.ks_log2 = a.ksplit == 8 ? 3 : a.ksplit == 4 ? 2 : a.ksplit == 2 ? 1 : 0;
     a.inv_cols = 1.0 / (double)w.cols;
@@ -699,7 +701,9 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     const size_t lds = (size_t)nw * (bs32 ? 5 : 4) * (ring_t * 256 + 16) + 2 * nw * sizeof(double) + nw * 16 * sizeof(float) +
                        ((ln && !ln2) ? w.cols * sizeof(float) : 0);
     if (lds > 64 * 1024) {
+        static std::mutex raised_mu;                     // launches may come from several host threads (Send + Sync)
         static std::unordered_set<const void *> raised;  // raised once per kernel, outside any capture
+        std::lock_guard<std::mutex> lk(raised_mu);
         if (!raised.count((const void *)kfn)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;

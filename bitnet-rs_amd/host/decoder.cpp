@@ -11,6 +11,15 @@
 
 namespace bitnet_host {
 
+namespace {
+struct Event {  // RAII: an error return between create and destroy must not leak the event
+    hipEvent_t e = nullptr;
+    ~Event() {
+        if (e) hipEventDestroy(e);
+    }
+};
+}  // namespace
+
 #define HCHK(expr)                                                                     \
     do {                                                                               \
         hipError_t _e = (expr);                                                        \
@@ -38,7 +47,27 @@ static hipError_t dalloc(T **p, size_t n) {
     return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T) ? n * sizeof(T) : 1);
 }
 
-Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
+static std::string config_problem(const Config &c) {
+    char b[160];
+    if (c.hidden <= 0 || c.n_layers <= 0 || c.n_heads <= 0 || c.n_kv_heads <= 0 || c.head_dim <= 0 || c.ffn <= 0 || c.vocab <= 0 || c.max_pos <= 1) {
+        snprintf(b, sizeof(b), "config: every dimension must be positive (hidden %d, layers %d, heads %d/%d, head_dim %d, ffn %d, vocab %d, max_pos %d)",
+                 c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.vocab, c.max_pos);
+        return b;
+    }
+    if (c.n_heads % c.n_kv_heads != 0) return "config: num_heads must be divisible by num_key_value_heads";  // T:215-220
+    if (c.head_dim != 128) return "config: head_dim must be 128 (attention kernels)";
+    if (c.n_heads / c.n_kv_heads > 4) return "config: at most 4 query heads per KV head (attention kernels)";
+    if (c.hidden % 512 != 0 || c.hidden > 8192) return "config: hidden must be a multiple of 512, <= 8192 (logits kernel)";
+    if (c.n_layers > 4096 || c.max_pos > (1 << 20)) return "config: n_layers / max_pos out of range";
+    return "";
+}
+
+Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n_layers <= 4096 ? (size_t)cfg.n_layers : 0) {
+    err_ = config_problem(cfg);
+    if (!err_.empty()) {
+        layers_.clear();
+        return;
+    }
     if (const char *e = getenv("BITNET_HOST_LOGITS_WGS")) logits_wgs_ = atoi(e) > 0 ? atoi(e) : logits_wgs_;  // tuning knob
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
@@ -63,6 +92,8 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
     ok &= dalloc(&qkv_, (size_t)(c_.n_heads + 2 * c_.n_kv_heads) * D) == hipSuccess;
     ok &= dalloc(&att_, (size_t)c_.n_heads * D) == hipSuccess;
     ok &= dalloc(&h_, (size_t)c_.ffn) == hipSuccess;
+    ok &= dalloc(&ref_n_, H > (size_t)c_.ffn ? H : (size_t)c_.ffn) == hipSuccess && dalloc(&ref_gu_, 2 * (size_t)c_.ffn) == hipSuccess &&
+          dalloc(&ref_t_, H) == hipSuccess;
     ok &= dalloc(&logits_, (size_t)c_.vocab) == hipSuccess;
     ok &= hipMalloc(&scratch_, 8 * (size_t)logits_wgs_) == hipSuccess;
     {
@@ -103,10 +134,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_((size_t)cfg.n_layers) {
 }
 
 Decoder::~Decoder() {
-    for (int i = 0; i < 6; ++i) {
-        if (graph_exec_[i]) hipGraphExecDestroy((hipGraphExec_t)graph_exec_[i]);
-        if (graph_[i]) hipGraphDestroy((hipGraph_t)graph_[i]);
-    }
+    drop_graphs();
     for (auto &L : layers_) {
         for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down})
             if (h) bitnet_hip_weights_free(h);
@@ -114,7 +142,7 @@ Decoder::~Decoder() {
             if (p) hipFree(p);
     }
     for (void *p : {(void *)embed_, (void *)final_norm_, (void *)rope_sin_, (void *)rope_cos_, (void *)x_, (void *)x2_,
-                    (void *)qkv_, (void *)att_, (void *)h_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
+                    (void *)qkv_, (void *)att_, (void *)h_, (void *)ref_n_, (void *)ref_gu_, (void *)ref_t_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
@@ -122,55 +150,45 @@ Decoder::~Decoder() {
     if (stream_) hipStreamDestroy((hipStream_t)stream_);
 }
 
-int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
-    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
-    Layer &L = layers_[(size_t)layer];
-    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
-    auto stride = [](size_t cols) { return (cols + 255) / 256 * 64; };
-    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
-    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
-    bitnet_hip_weights_t q = 0, k = 0, v = 0, g = 0, u = 0;
-    BCHK(bitnet_hip_weights_upload_qk256(w.q, QD * stride(H), QD, H, stride(H), &q));
-    BCHK(bitnet_hip_weights_upload_qk256(w.k, KD * stride(H), KD, H, stride(H), &k));
-    BCHK(bitnet_hip_weights_upload_qk256(w.v, KD * stride(H), KD, H, stride(H), &v));
-    BCHK(bitnet_hip_weights_upload_qk256(w.o, H * stride(QD), H, QD, stride(QD), &L.o));
-    BCHK(bitnet_hip_weights_upload_qk256(w.gate, F * stride(H), F, H, stride(H), &g));
-    BCHK(bitnet_hip_weights_upload_qk256(w.up, F * stride(H), F, H, stride(H), &u));
-    BCHK(bitnet_hip_weights_upload_qk256(w.down, H * stride(F), H, F, stride(F), &L.down));
-    const bitnet_hip_weights_t qkv[3] = {q, k, v}, gu[2] = {g, u};
-    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
-    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
-    for (bitnet_hip_weights_t h : {q, k, v, g, u}) bitnet_hip_weights_free(h);
-    size_t b = 0;
-    for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down}) {
+// A layer that already holds weights gives them back first, and every captured step graph goes (the graphs
+// hold the OLD matrices' device pointers).
+void Decoder::release_layer(Layer &L) {
+    for (bitnet_hip_weights_t *h : {&L.qkv, &L.o, &L.gateup, &L.down}) {
+        if (!*h) continue;
         size_t ab = 0;
-        bitnet_hip_weights_info(h, nullptr, nullptr, &ab);
-        b += ab;
+        if (bitnet_hip_weights_info(*h, nullptr, nullptr, &ab) == 0) weight_bytes_ -= ab < weight_bytes_ ? ab : weight_bytes_;
+        bitnet_hip_weights_free(*h);
+        *h = 0;
     }
-    weight_bytes_ += b;
-    BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
-    BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
-    return 0;
+    drop_graphs();
 }
 
-int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
-    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
-    Layer &L = layers_[(size_t)layer];
-    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
-    const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
-    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
-    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
-    bitnet_hip_weights_t h[7] = {0};
-    for (int i = 0; i < 7; ++i) {
-        const size_t pk = (k[i] + 3) / 4, nb = (k[i] + w.block_size - 1) / w.block_size;
-        BCHK(bitnet_hip_weights_upload_i2s(w.w[i], pk * n[i], w.scales[i], nb * n[i], n[i], k[i], w.block_size, &h[i]));
+void Decoder::drop_graphs() {
+    for (int i = 0; i < kGraphs; ++i) {
+        if (graph_exec_[i]) hipGraphExecDestroy((hipGraphExec_t)graph_exec_[i]);
+        if (graph_[i]) hipGraphDestroy((hipGraph_t)graph_[i]);
+        graph_exec_[i] = graph_[i] = nullptr;
     }
+}
+
+// the four fused handles of a layer from its seven uploaded projections; frees the seven on every path
+int Decoder::adopt_projections(Layer &L, bitnet_hip_weights_t h[7]) {
     const bitnet_hip_weights_t qkv[3] = {h[0], h[1], h[2]}, gu[2] = {h[4], h[5]};
-    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
-    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
-    L.o = h[3];
-    L.down = h[6];
-    for (int i : {0, 1, 2, 4, 5}) bitnet_hip_weights_free(h[i]);
+    int rc = bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv);
+    if (!rc) rc = bitnet_hip_weights_concat(gu, 2, 1, &L.gateup);
+    if (!rc) {
+        L.o = h[3];
+        L.down = h[6];
+        h[3] = h[6] = 0;
+    }
+    const std::string keep = rc ? (bitnet_hip_get_last_error() ? bitnet_hip_get_last_error() : "error") : "";
+    for (int i = 0; i < 7; ++i)
+        if (h[i]) bitnet_hip_weights_free(h[i]), h[i] = 0;
+    if (rc) {
+        release_layer(L);
+        err_ = "weights_concat: " + keep;
+        return BITNET_HIP_ERR_EXECUTION;
+    }
     for (bitnet_hip_weights_t hh : {L.qkv, L.o, L.gateup, L.down}) {
         size_t ab = 0;
         bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
@@ -180,6 +198,47 @@ int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
     BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
     BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
     return 0;
+}
+
+int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
+    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    Layer &L = layers_[(size_t)layer];
+    release_layer(L);
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    auto stride = [](size_t cols) { return (cols + 255) / 256 * 64; };
+    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
+    bitnet_hip_weights_t h[7] = {0};
+    const uint8_t *src[7] = {w.q, w.k, w.v, w.o, w.gate, w.up, w.down};
+    const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
+    for (int i = 0; i < 7; ++i) {
+        if (bitnet_hip_weights_upload_qk256(src[i], n[i] * stride(k[i]), n[i], k[i], stride(k[i]), &h[i]) != 0) {
+            const int rc = fail("bitnet_hip_weights_upload_qk256");
+            for (int j = 0; j < i; ++j) bitnet_hip_weights_free(h[j]);
+            return rc;
+        }
+    }
+    return adopt_projections(L, h);
+}
+
+int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
+    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    Layer &L = layers_[(size_t)layer];
+    release_layer(L);
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
+    HCHK(hipMemcpy(L.attn_norm, w.attn_norm, H * 4, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(L.ffn_norm, w.ffn_norm, H * 4, hipMemcpyHostToDevice));
+    bitnet_hip_weights_t h[7] = {0};
+    for (int i = 0; i < 7; ++i) {
+        const size_t pk = (k[i] + 3) / 4, nb = (k[i] + w.block_size - 1) / w.block_size;
+        if (bitnet_hip_weights_upload_i2s(w.w[i], pk * n[i], w.scales[i], nb * n[i], n[i], k[i], w.block_size, &h[i]) != 0) {
+            const int rc = fail("bitnet_hip_weights_upload_i2s");
+            for (int j = 0; j < i; ++j) bitnet_hip_weights_free(h[j]);
+            return rc;
+        }
+    }
+    return adopt_projections(L, h);
 }
 
 int Decoder::set_layer_specs(int layer, const float *attn_norm, const float *ffn_norm, const ProjSpec p[7]) {
@@ -191,33 +250,25 @@ int Decoder::set_layer_specs(int layer, const float *attn_norm, const float *ffn
         err_ = "q|k|v (and gate|up) must share one I2_S flavour to be fused";
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
     }
+    release_layer(L);
     HCHK(hipMemcpy(L.attn_norm, attn_norm, H * 4, hipMemcpyHostToDevice));
     HCHK(hipMemcpy(L.ffn_norm, ffn_norm, H * 4, hipMemcpyHostToDevice));
     bitnet_hip_weights_t h[7] = {0};
     for (int i = 0; i < 7; ++i) {
+        int rc;
         if (p[i].qk256) {
             const size_t stride = (k[i] + 255) / 256 * 64;
-            BCHK(bitnet_hip_weights_upload_qk256(p[i].bytes, p[i].len, n[i], k[i], stride, &h[i]));
+            rc = bitnet_hip_weights_upload_qk256(p[i].bytes, p[i].len, n[i], k[i], stride, &h[i]);
         } else {
-            BCHK(bitnet_hip_weights_upload_coded(p[i].bytes, p[i].len, p[i].scales, p[i].n_scales, n[i], k[i], p[i].block,
-                                                 p[i].code_map, &h[i]));
+            rc = bitnet_hip_weights_upload_coded(p[i].bytes, p[i].len, p[i].scales, p[i].n_scales, n[i], k[i], p[i].block, p[i].code_map, &h[i]);
+        }
+        if (rc != 0) {
+            rc = fail("weights upload");
+            for (int j = 0; j < i; ++j) bitnet_hip_weights_free(h[j]);
+            return rc;
         }
     }
-    const bitnet_hip_weights_t qkv[3] = {h[0], h[1], h[2]}, gu[2] = {h[4], h[5]};
-    BCHK(bitnet_hip_weights_concat(qkv, 3, 0, &L.qkv));
-    BCHK(bitnet_hip_weights_concat(gu, 2, 1, &L.gateup));
-    L.o = h[3];
-    L.down = h[6];
-    for (int i : {0, 1, 2, 4, 5}) bitnet_hip_weights_free(h[i]);
-    for (bitnet_hip_weights_t hh : {L.qkv, L.o, L.gateup, L.down}) {
-        size_t ab = 0;
-        bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
-        weight_bytes_ += ab;
-    }
-    // LayerNorm applied after the product for the two normalised projections (bitnet_hip_weights_bind_ln)
-    BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
-    BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
-    return 0;
+    return adopt_projections(L, h);
 }
 
 int Decoder::set_globals(const uint16_t *embed_f16, const float *final_norm) {
@@ -240,6 +291,17 @@ int Decoder::feed(const int32_t *tokens, int n) {
     const int p = position();
     if (p < 0) return BITNET_HIP_ERR_GPU;
     const int base = p > host_forced_ ? p : host_forced_;
+    if (n < 0 || (n > 0 && !tokens)) {
+        err_ = "feed: null tokens";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    for (int i = 0; i < n; ++i)
+        if (tokens[i] < 0 || tokens[i] >= c_.vocab) {  // TransformerModel::embed's index_select fails on it (T:1390-1426)
+            char b[96];
+            snprintf(b, sizeof(b), "token id %d out of range [0, %d)", tokens[i], c_.vocab);
+            err_ = b;
+            return BITNET_HIP_ERR_INVALID_ARGUMENT;
+        }
     if (base + n > c_.max_pos) {
         err_ = "KV cache overflow";  // T:1190-1194
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
@@ -297,6 +359,60 @@ int Decoder::step_launches(bool with_logits, int form) {
     return 0;
 }
 
+// The same step UNFUSED, in the reference's own op order (T:977-1134), every projection on the reference-order kernel
+// (BITNET_HIP_KERNEL_EXACT: bit-identical to the scalar CPU loops): LayerNorm rows -> GEMV -> attention -> GEMV ->
+// residual add -> LayerNorm rows -> GEMV (gate|up tiles) -> silu*mul -> GEMV -> residual add.  Slow (one thread per
+// output row); bench.py and the tests hold the fast step's logits against it at the full model size.
+int Decoder::step_launches_reference(bool with_logits) {
+    void *s = stream_;
+    const size_t H = c_.hidden, F = c_.ffn;
+    const int K = BITNET_HIP_KERNEL_EXACT;
+    BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
+    for (auto &L : layers_) {
+        BCHK(bitnet_hip_norm_rows_dev(x_, L.attn_norm, ref_n_, 1, H, c_.eps, 0, s));
+        BCHK(bitnet_hip_matmul_kernel_dev(L.qkv, ref_n_, qkv_, 1, K, s));
+        BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                             (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+        BCHK(bitnet_hip_matmul_kernel_dev(L.o, att_, ref_t_, 1, K, s));
+        BCHK(bitnet_hip_add_dev(x_, ref_t_, x2_, H, s));
+        BCHK(bitnet_hip_norm_rows_dev(x2_, L.ffn_norm, ref_n_, 1, H, c_.eps, 0, s));
+        BCHK(bitnet_hip_matmul_kernel_dev(L.gateup, ref_n_, ref_gu_, 1, K, s));  // alternating 16-row (gate, up) tiles
+        BCHK(bitnet_hip_silu_mul_dev(ref_gu_, ref_gu_ + 16, h_, F, 16, s));
+        BCHK(bitnet_hip_matmul_kernel_dev(L.down, h_, ref_t_, 1, K, s));
+        BCHK(bitnet_hip_add_dev(x2_, ref_t_, x_, H, s));
+    }
+    if (with_logits) {
+        BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_, pos_,
+                                       history_, n_forced_, s));
+    } else {
+        BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+    }
+    return 0;
+}
+
+int Decoder::run_reference(int n, bool with_logits) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (c_.ffn % 16 != 0) {
+        err_ = "run_reference: ffn must be a multiple of 16";
+        return BITNET_HIP_ERR_UNSUPPORTED;
+    }
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    if (p + n > c_.max_pos - 1) {
+        err_ = "KV cache overflow";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = step_launches_reference(with_logits);
+        if (rc) return rc;
+    }
+    HCHK(hipStreamSynchronize((hipStream_t)stream_));
+    return 0;
+}
+
 // Which attention form a step at `pos` (pos + 1 keys) takes; the host knows every step's position.
 int Decoder::form_at(int pos) const {
     static const bool merge_env = !(getenv("BITNET_HOST_ATTN_MERGE") && atoi(getenv("BITNET_HOST_ATTN_MERGE")) == 0);
@@ -338,6 +454,11 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
         err_ = "KV cache overflow";  // T:1190-1194
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
     }
+    if (!with_logits && p + n > host_forced_) {
+        // a step without logits samples nothing: the NEXT position's token must already be in the history
+        err_ = "run(with_logits = false) past the fed tokens: nothing would choose the next token";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
     hipStream_t s = (hipStream_t)stream_;
     if (use_graph) {
         for (int i = 0; i < n; ++i) {  // every form this run needs (at most three captures)
@@ -345,9 +466,10 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
             if (rc) return rc;
         }
     }
-    hipEvent_t e0, e1;
-    HCHK(hipEventCreate(&e0));
-    HCHK(hipEventCreate(&e1));
+    Event ev0, ev1;
+    HCHK(hipEventCreate(&ev0.e));
+    HCHK(hipEventCreate(&ev1.e));
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     HCHK(hipEventRecord(e0, s));
     for (int i = 0; i < n; ++i) {
         if (use_graph) {
@@ -362,8 +484,6 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, e0, e1));
     if (elapsed_ms) *elapsed_ms = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     return 0;
 }
 
@@ -405,9 +525,10 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         pf_cap_ = n;
     }
     hipStream_t s = (hipStream_t)stream_;
-    hipEvent_t e0, e1;
-    HCHK(hipEventCreate(&e0));
-    HCHK(hipEventCreate(&e1));
+    Event ev0, ev1;
+    HCHK(hipEventCreate(&ev0.e));
+    HCHK(hipEventCreate(&ev1.e));
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     HCHK(hipEventRecord(e0, s));
     const size_t N = (size_t)n;
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, N, H, (size_t)c_.vocab, pf_x_, s));  // *pos_ == 0
@@ -429,8 +550,6 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, e0, e1));
     if (elapsed_ms) *elapsed_ms = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     return 0;
 }
 
@@ -467,6 +586,10 @@ void Decoder::global_objects(void *ptrs[7]) const {
 }
 
 int Decoder::history(int32_t *out, int n) {
+    if (!out || n < 0 || n > c_.max_pos + 2) {
+        err_ = "history: n out of range";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
     HCHK(hipMemcpy(out, history_, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -572,7 +695,13 @@ void *bitnet_host_create(const bitnet_host_config *cfg) {
     c.max_pos = cfg->max_pos;
     c.eps = cfg->eps;
     c.rope_theta = cfg->rope_theta;
-    return new Decoder(c);
+    // Nothing is thrown across the C boundary: a configuration the kernels cannot take comes back as a decoder
+    // whose error() says why (every later call on it fails), allocation failures as nullptr.
+    try {
+        return new Decoder(c);
+    } catch (...) {
+        return nullptr;
+    }
 }
 void bitnet_host_destroy(void *d) { delete static_cast<Decoder *>(d); }
 const char *bitnet_host_error(void *d) { return static_cast<Decoder *>(d)->error().c_str(); }
@@ -599,6 +728,7 @@ int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *fin
 }
 int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
 int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
+int bitnet_host_run_reference(void *d, int n, int with_logits) { return static_cast<Decoder *>(d)->run_reference(n, with_logits != 0); }
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);
 }

@@ -79,6 +79,9 @@ class Decoder {
     // logits GEMV for prompt positions nobody samples from.  Uses the captured graph
     // when use_graph, else eager launches.  Synchronises the stream before returning.
     int run(int n, bool with_logits, bool use_graph, float *elapsed_ms);
+    // The same n steps UNFUSED, in the reference's op order, every projection on the reference-order (bit-exact)
+    // kernel: the checker bench.py and the tests hold the fast step against at the full model size.  Eager, slow.
+    int run_reference(int n, bool with_logits);
     // Whole-prompt forward on a fresh sequence (position() == 0): the first n fed tokens go
     // through every layer as [n, *] matrices (TransformerModel::forward with seq_len n,
     // T:1557-1597): tiled matmuls + causal attention, KV cache filled for positions 0..n-1.
@@ -113,6 +116,7 @@ class Decoder {
     // attention form of a step: 0 = two kernels, 64-position chunks; 1 = one kernel + merging o-projection (short
     // contexts); 2 = two kernels, 128-position chunks (more chunks than CUs)
     int step_launches(bool with_logits, int form);
+    int step_launches_reference(bool with_logits);
     int ensure_graph(bool with_logits, int form);
     int form_at(int pos) const;
     bool merge_ok_ = false;  // the o-projection can merge the attention chunk records itself (short contexts)
@@ -125,11 +129,15 @@ class Decoder {
         bitnet_hip_weights_t qkv = 0, o = 0, gateup = 0, down = 0;
         float *kcache = nullptr, *vcache = nullptr;
     };
+    void release_layer(Layer &L);  // frees the layer's handles, subtracts their bytes, drops the captured graphs
+    void drop_graphs();
+    int adopt_projections(Layer &L, bitnet_hip_weights_t h[7]);
     std::vector<Layer> layers_;
     void *embed_ = nullptr;
     float *final_norm_ = nullptr;
     float *rope_sin_ = nullptr, *rope_cos_ = nullptr;
     float *x_ = nullptr, *x2_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *h_ = nullptr, *logits_ = nullptr;
+    float *ref_n_ = nullptr, *ref_gu_ = nullptr, *ref_t_ = nullptr;  // unfused reference step: normalised row, gate|up tiles, projection out
     void *scratch_ = nullptr;
     float *attn_scratch_ = nullptr;
     int32_t *pos_ = nullptr, *n_forced_ = nullptr, *history_ = nullptr, *token_ = nullptr;
@@ -140,8 +148,9 @@ class Decoder {
     void *pf_gemm_ws_ = nullptr, *pf_attn_ws_ = nullptr;
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;
-    void *graph_exec_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [2 * form + with_logits]
-    void *graph_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kGraphs = 6;
+    void *graph_exec_[kGraphs] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [2 * form + with_logits]
+    void *graph_[kGraphs] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int logits_wgs_ = 512;  // two workgroups per CU: whole rounds on the 256 CUs (768 / 1280 workgroups are 15-20 % slower)
 };
 
@@ -165,6 +174,7 @@ int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *fin
 int bitnet_host_reset(void *d);
 int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
+int bitnet_host_run_reference(void *d, int n, int with_logits);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);
 void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4);

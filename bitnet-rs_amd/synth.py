@@ -3,8 +3,9 @@ environment; SURVEY.md 8d fixes the recipe).  Data only: no arithmetic of the pa
 
   * I2_S codes: uniform 2-bit codes from a counter-based PRNG, seed 42, one stream per
     tensor (crates/bitnet-models/tests/qk256_avx2_correctness.rs:72-88 uses uniform codes);
-  * norm gammas ~ U(0.5, 1.5) / (1.58 * sqrt(hidden)) so that projections of a
-    normalised vector stay O(1) with unscaled {-2,-1,+1,+2} weights;
+  * norm gammas ~ U(0.5, 1.5) / (w_rms * sqrt(hidden)), w_rms = the format's weight rms
+    (1.58 for unscaled {-2,-1,+1,+2}, 0.181 for ternary x block scales), so that projections
+    of a normalised vector stay O(1) and greedy tokens vary;
   * tied embedding table f16 ~ N(0, 1);
   * prompt ids (1000 + 37 i) mod vocab with BOS first.
 """
@@ -68,9 +69,17 @@ def ternary_weights(rows: int, cols: int, block: int, seed: int, layer: int, pro
     return packed.reshape(-1), scales
 
 
+# rms of one weight: QK256 codes uniform over {-2,-1,+1,+2} -> sqrt(2.5) = 1.58; ternary {0,+-1} with P(+-1) = .5 times the
+# scales 2/((i%100)+1) -> sqrt(.5 * mean(s^2)) = sqrt(.5 * 4 * 0.01635) = 0.181
+W_RMS = {"qk256": 1.58, "i2s": 0.181}
+
+
 def make_layer(cfg: ModelConfig, layer: int, seed: int = 42, fmt: str = "qk256", block: int = 32) -> dict:
     g = _stream(seed, layer, 100)
-    norm_scale = 1.0 / (1.58 * np.sqrt(cfg.hidden))
+    # gammas sized for the format's weight rms, so that the projections of a normalised vector are O(1) in BOTH formats
+    # (round 1 used the QK256 figure for the ternary format too: projections ~0.1, the residual stream stayed the token's own
+    # embedding and the tied logits returned the input token forever)
+    norm_scale = 1.0 / (W_RMS["qk256" if fmt == "qk256" else "i2s"] * np.sqrt(cfg.hidden))
     out = {
         "attn_norm": (g.uniform(0.5, 1.5, cfg.hidden) * norm_scale).astype(np.float32),
         "ffn_norm": (g.uniform(0.5, 1.5, cfg.hidden) * norm_scale).astype(np.float32),

@@ -91,7 +91,7 @@ int bitnet_hip_get_device_info(int device, bitnet_hip_device_info *out);
  * Q/i2s_qk256.rs:346-353 (live call sites T:684, T:924,
  * crates/bitnet-inference/src/layers/quantized_linear.rs:572).
  * y[r] = sum_j LUT[code(r,j)] * x[j], LUT {-2,-1,+1,+2}, LSB-first 2-bit codes,
- * tail cols%256 ignored.  Error text keeps the substrings the reference's tests
+ * a ragged tail (cols % 256 != 0) is summed like the reference's `take(cols)`.  Error text keeps the substrings the reference's tests
  * assert ("y_out length", "x length", "too short"; Q/i2s_qk256.rs:701-739). */
 int bitnet_hip_gemv_qk256(const uint8_t *qs_data, size_t qs_len, const float *x, size_t x_len,
                           float *y_out, size_t y_len, size_t rows, size_t cols,
@@ -189,6 +189,11 @@ int bitnet_hip_gemv_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev
  * batched; row-major, leading dimensions cols / rows) */
 int bitnet_hip_matmul_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                           void *stream);
+/* The same with the kernel named per call (BITNET_HIP_KERNEL_*) instead of the process-wide default of
+ * bitnet_hip_set_kernel: what a multi-threaded host uses (the trait is Send + Sync, K/lib.rs:39), and how
+ * bench.py / the tests run an UNFUSED step on the bit-exact reference-order kernel next to the fast one. */
+int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
+                                 int kernel, void *stream);
 /* Many activation rows at once (prefill; forward_qk256's per-row loop T:683-691 as ONE tiled
  * matmul on the matrix cores).  Same fusions as gemv_fused_dev, per row.  `digits` = base-256
  * fixed-point digits per activation (4: the GEMV's 30 bits; 3: 22 bits; 2: 14 bits).
@@ -257,6 +262,13 @@ int bitnet_hip_norm_rows_dev(const float *x_dev, const float *gamma_dev, float *
 int bitnet_hip_embed_f16_dev(const void *table_f16_dev, const int32_t *tokens_dev,
                              const int32_t *offset_dev, size_t n, size_t hidden, size_t vocab,
                              float *out_dev, void *stream);
+/* The two elementwise steps of the reference's UNFUSED block (the fast path fuses them into GEMV epilogues):
+ * out = a + b (residual add, T:1073, T:1125); out[i] = silu(gate[.]) * up[.] (T:765-781) -- tile == 0: separate
+ * vectors; tile > 0: gate_dev is ONE vector of alternating `tile`-row groups (gate, up, gate, ...) as a plain GEMV
+ * on a weights_concat(..., interleave16 = 1) handle produces it (tile = 16), up_dev = gate_dev + tile. */
+int bitnet_hip_add_dev(const float *a_dev, const float *b_dev, float *out_dev, size_t n, void *stream);
+int bitnet_hip_silu_mul_dev(const float *gate_dev, const float *up_dev, float *out_dev, size_t n, size_t tile,
+                            void *stream);
 /* *pos_dev += 1 (prompt positions whose logits nobody reads). */
 int bitnet_hip_advance_pos_dev(int32_t *pos_dev, void *stream);
 /* One new token through MultiHeadAttention::forward's core (T:373-540): RoPE on q,k with
