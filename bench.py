@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
+    ap.add_argument("--exact-act", action="store_true", help="exact f32 activations between the kernels (round 1's path) instead of QAct")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU) BEFORE anything here
@@ -258,6 +259,8 @@ def main():
     global PROMPT_LEN
     PROMPT_LEN = args.prompt or {"c4": 4096, "c5": 8192}.get(args.workload, 128)
     cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers)
+    if args.exact_act:
+        dec.set_act_mode(0)
     if args.workload == "c5":
         return bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec)
     assert PROMPT_LEN + args.warmup + args.steps + 2 < cfg.max_pos
@@ -295,7 +298,7 @@ def main():
     achieved = abytes / us / 1e3  # GB/s
     roofline = {
         "bound": "hbm",
-        "kernel": "k_gemv_mfma (fused LayerNorm -> gate|up GEMV -> silu*mul)",
+        "kernel": ("k_gemv_q" if dec.act_mode() else "k_gemv_mfma") + " (fused LayerNorm -> gate|up GEMV -> silu*mul)",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -332,7 +335,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i8 MFMA on exact 30-bit fixed-point activations, f32 accumulate / f32 elsewhere (f16 embedding table)",
+            "dtype": ("i8 MFMA on producer-quantised activations (QAct: 15-bit fixed point per element, one power-of-two scale per 16), exact integer "
+                      "partial sums, f32 accumulate / f32 elsewhere (f16 embedding table)") if dec.act_mode() else
+                     "i8 MFMA on exact 30-bit fixed-point activations, f32 accumulate / f32 elsewhere (f16 embedding table)",
             "data": "synthetic",
             "config": {
                 "workload": f"bitnet-b1.58-2B-4T I2_S BitNet32-F16 (ternary, one f16 scale per 32 weights), {n_gpus}xMI355X, batch=1 decode, {PROMPT_LEN}-token prompt"

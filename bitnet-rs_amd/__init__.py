@@ -84,6 +84,11 @@ def _ptr(t):
     return _vp(t if isinstance(t, int) else t.data_ptr())
 
 
+def _optr(t):
+    """Nullable device pointer."""
+    return None if t is None else _ptr(t)
+
+
 class HipLib:
     """ctypes view of libbitnet_hip.so.  One method per exported symbol."""
 
@@ -119,6 +124,16 @@ class HipLib:
         L.bitnet_hip_matmul_kernel_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, C.c_int, _vp]
         L.bitnet_hip_add_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
         L.bitnet_hip_silu_mul_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp]
+        L.bitnet_hip_qact_bytes.argtypes = [_sz]
+        L.bitnet_hip_qact_bytes.restype = _sz
+        L.bitnet_hip_qact_stats_bytes.argtypes = [_sz]
+        L.bitnet_hip_qact_stats_bytes.restype = _sz
+        L.bitnet_hip_quantize_act_dev.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
+        L.bitnet_hip_embed_q_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_gemv_q_supported.argtypes = [C.c_uint64]
+        L.bitnet_hip_gemv_q_dev.argtypes = [C.c_uint64, _vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_attention_decode_q_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, C.c_int, _vp, _vp, _vp]
+        L.bitnet_hip_gemv_attn_merge_q_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
@@ -340,6 +355,38 @@ class HipLib:
     def silu_mul_dev(self, gate, up, out, n: int, tile: int = 0, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_silu_mul_dev(_ptr(gate), _ptr(up), _ptr(out), n, tile, _vp(stream)))
 
+    # ---- QAct: activations quantised by their producer (csrc/qact.hpp) ----
+    def qact_bytes(self, cols: int) -> int:
+        return int(self.c.bitnet_hip_qact_bytes(cols))
+
+    def qact_stats_bytes(self, cols: int) -> int:
+        return int(self.c.bitnet_hip_qact_stats_bytes(cols))
+
+    def quantize_act_dev(self, x, gamma, cols: int, qact_out, stats_out=None, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_quantize_act_dev(_ptr(x), _optr(gamma), cols, _ptr(qact_out), _optr(stats_out), _vp(stream)))
+
+    def embed_q_dev(self, table, tokens, x_out, hidden: int, vocab: int, gamma, qact_out, stats_out=None, offset=None, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_embed_q_dev(_ptr(table), _ptr(tokens), _optr(offset), hidden, vocab, _ptr(x_out), _optr(gamma), _ptr(qact_out),
+                                                  _optr(stats_out), _vp(stream)))
+
+    def gemv_q_supported(self, h: int) -> bool:
+        return bool(self.c.bitnet_hip_gemv_q_supported(h))
+
+    def gemv_q_dev(self, h: int, qact_in, y=None, stats_in=None, ln_gamma=None, ln_eps: float = 0.0, residual=None, flags: int = 0, qact_out=None,
+                   gamma_out=None, stats_out=None, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_gemv_q_dev(h, _ptr(qact_in), _optr(stats_in), _optr(ln_gamma), ln_eps, _optr(residual), flags, _optr(y),
+                                                 _optr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
+
+    def attention_decode_q_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, qact_out,
+                               wide: bool = False, stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_attention_decode_q_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
+                                                             head_dim, max_pos, _ptr(pos), _ptr(scratch), int(wide), _optr(out), _optr(qact_out), _vp(stream)))
+
+    def gemv_attn_merge_q_dev(self, h: int, scratch, n_heads, n_kv, max_pos, pos, y, qact_out, residual=None, gamma_out=None, stats_out=None,
+                              stream: int = 0) -> None:
+        self._check(self.c.bitnet_hip_gemv_attn_merge_q_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _optr(residual),
+                                                            _ptr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
+
     def weights_concat(self, parts, interleave16: bool = False) -> int:
         arr = (C.c_uint64 * len(parts))(*parts)
         h = C.c_uint64(0)
@@ -532,6 +579,8 @@ class HostDecoder:
         L.bitnet_host_feed.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.bitnet_host_run_reference.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bitnet_host_set_act_mode.argtypes = [C.c_void_p, C.c_int]
+        L.bitnet_host_act_mode.argtypes = [C.c_void_p]
         L.bitnet_host_position.argtypes = [C.c_void_p]
         L.bitnet_host_history.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_last_logits.argtypes = [C.c_void_p, _f32p]
@@ -594,6 +643,13 @@ class HostDecoder:
         ms = C.c_float(0)
         self._check(self.c.bitnet_host_run(self.h, n, int(with_logits), int(use_graph), C.byref(ms)))
         return ms.value
+
+    def set_act_mode(self, mode: int) -> None:
+        """1 (default): activations quantised once by their producer (QAct); 0: exact f32 activations."""
+        self._check(self.c.bitnet_host_set_act_mode(self.h, mode))
+
+    def act_mode(self) -> int:
+        return int(self.c.bitnet_host_act_mode(self.h))
 
     def run_reference(self, n: int, with_logits: bool = True) -> None:
         """n UNFUSED steps on the bit-exact reference-order kernels (the checker of the fast step; slow)."""

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "qact.hpp"
 
 namespace bitnet_hip {
 
@@ -687,8 +688,9 @@ int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_
 
 size_t bitnet_hip_attention_merge_max_keys(void) { return (size_t)4 * 64; }
 
-int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
-                                   size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *stream) {
+static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads, size_t max_pos,
+                           const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out, const float *gamma_out_dev,
+                           double *stats_out, void *stream) {
     BH_GUARD_BEGIN
     const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
@@ -699,6 +701,8 @@ int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scr
                          n_heads, n_kv_heads);
     if (!mfma_supported(*w) || div_ceil(div_ceil(w->cols, 256), (size_t)8) > 2)
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_dev: matrix shape %zux%zu not supported", w->rows, w->cols);
+    if (qact_out && w->rows % 16 != 0)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_q_dev: rows %zu must be a multiple of 16 for a QAct output", w->rows);
     GemvFusion fu;
     fu.residual = residual_dev;
     fu.attn_rec = attn_scratch_dev;
@@ -706,7 +710,101 @@ int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scr
     fu.attn_chunk_log2 = 6;
     fu.attn_chunks_max = (int)div_ceil(max_pos, (size_t)1 << fu.attn_chunk_log2);
     fu.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
-    return run_gemv(*w, attn_scratch_dev, y_dev, 1, fu, (hipStream_t)stream);
+    fu.qout = qact_out;
+    fu.gamma_out = gamma_out_dev;
+    fu.stats_out = stats_out;
+    return run_gemv(*w, attn_scratch_dev, y_dev, 1, fu, (hipStream_t)stream, BITNET_HIP_KERNEL_MFMA);
+    BH_GUARD_END
+}
+
+int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
+                                   size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *stream) {
+    return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, nullptr, nullptr, nullptr, stream);
+}
+
+int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
+                                     size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out,
+                                     const float *gamma_out_dev, double *stats_out, void *stream) {
+    if (!qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_q_dev");
+    return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, qact_out, gamma_out_dev, stats_out, stream);
+}
+
+/* ---- QAct: activations quantised by their producer (csrc/qact.hpp) ---- */
+
+size_t bitnet_hip_qact_bytes(size_t cols) { return qact_bytes(cols); }
+size_t bitnet_hip_qact_stats_bytes(size_t cols) { return div_ceil(cols, 16) * 2 * sizeof(double); }
+
+int bitnet_hip_quantize_act_dev(const float *x_dev, const float *gamma_dev, size_t cols, void *qact_out, double *stats_out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!x_dev || !qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to quantize_act_dev");
+    if (cols == 0 || cols % 16 != 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "quantize_act: cols %zu must be a positive multiple of 16", cols);
+    BH_HIP_TRY(launch_quant_act(x_dev, gamma_dev, cols, qact_out, stats_out, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_embed_q_dev(const void *table, const int32_t *tokens_dev, const int32_t *offset_dev, size_t hidden, size_t vocab,
+                           float *x_out_dev, const float *gamma_dev, void *qact_out, double *stats_out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!table || !tokens_dev || !x_out_dev || !qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to embed_q_dev");
+    if (hidden == 0 || hidden % 16 != 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "embed_q: hidden %zu must be a positive multiple of 16", hidden);
+    BH_HIP_TRY(launch_embed_q(table, tokens_dev, offset_dev, (int)hidden, (int)vocab, x_out_dev, gamma_dev, qact_out, stats_out, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_gemv_q_supported(bitnet_hip_weights_t h) {
+    const WeightsRef w = lookup(h);
+    return w && gemvq_supported(*w) ? 1 : 0;
+}
+
+int bitnet_hip_gemv_q_dev(bitnet_hip_weights_t h, const void *qact_in, const double *stats_in, const float *ln_gamma_dev, float ln_eps,
+                          const float *residual_dev, int flags, float *y_dev, void *qact_out, const float *gamma_out_dev, double *stats_out,
+                          void *stream) {
+    BH_GUARD_BEGIN
+    const WeightsRef w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!qact_in || (!y_dev && !qact_out)) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_q_dev");
+    if (!gemvq_supported(*w))
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_q_dev: matrix %zux%zu (block %zu) is not on the QAct path (cols %% 256 == 0, rows %% 16 == 0, no scales or 32-element blocks)",
+                         w->rows, w->cols, w->block_size);
+    GemvQIo io;
+    io.qin = qact_in;
+    io.stats_in = stats_in;
+    io.ln_gamma = ln_gamma_dev;
+    io.ln_eps = ln_eps;
+    io.residual = residual_dev;
+    io.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    io.y = y_dev;
+    io.qout = qact_out;
+    io.gamma_out = gamma_out_dev;
+    io.stats_out = stats_out;
+    if (io.silu_mul && (!w->paired || residual_dev || w->rows % 32 != 0))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    if (ln_gamma_dev && (!stats_in || !w->ln_g || w->ln_gamma_bound != ln_gamma_dev))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "gemv_q_dev: LayerNorm needs stats_in and the gamma bound with bitnet_hip_weights_bind_ln");
+    if (ln_gamma_dev && w->cols > 4096)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_q_dev: LayerNorm input of %zu columns (<= 4096)", w->cols);
+    hipError_t e = launch_gemv_q(*w, io, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_attention_decode_q_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache, float *vcache,
+                                      size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos, const int32_t *pos_dev,
+                                      float *scratch, int wide, float *out, void *qact_out, void *stream) {
+    BH_GUARD_BEGIN
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch || (!out && !qact_out))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_q_dev");
+    if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
+    if (head_dim != 128 || n_heads / n_kv_heads > 4)
+        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
+                         head_dim, n_heads / n_kv_heads);
+    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, pos_dev,
+                                  scratch, out, (hipStream_t)stream, true, wide ? 2 : 1, qact_out));
+    return BITNET_HIP_OK;
     BH_GUARD_END
 }
 

@@ -89,6 +89,25 @@ struct GemvFusion {
     int attn_chunks_max = 0;          // records per KV head in the buffer
     int attn_chunk_log2 = 6;          // positions per record = 1 << attn_chunk_log2
     int attn_group_log2 = 0;          // query heads per KV head = 1 << attn_group_log2
+    // the output also goes out as a QAct (qact.hpp) for the next GEMV: qout records, the consumer's LayerNorm weight
+    // (nullable) and per-16-row (sum, sum of squares) pairs (nullable); rows % 16 == 0
+    void *qout = nullptr;
+    const float *gamma_out = nullptr;
+    double *stats_out = nullptr;
+};
+
+// Inputs / outputs of the GEMV on pre-quantised activations (kernels_gemvq.hip).
+struct GemvQIo {
+    const void *qin = nullptr;         // QAct records of the activation vector [cols]
+    const double *stats_in = nullptr;  // with ln_gamma: (sum, sum of squares) per 16 columns of the un-normalised vector
+    const float *ln_gamma = nullptr;   // LayerNorm of the consumer, applied after the product: must be the bound gamma
+    float ln_eps = 0.0f;
+    const float *residual = nullptr;
+    bool silu_mul = false;
+    float *y = nullptr;                // f32 output (nullable)
+    void *qout = nullptr;              // QAct output (nullable) ...
+    const float *gamma_out = nullptr;  // ... multiplied by the NEXT LayerNorm's weight first (nullable)
+    double *stats_out = nullptr;       // ... with its row statistics (nullable)
 };
 
 // ---- kernel launchers (kernels_*.hip) -------------------------------------
@@ -100,6 +119,12 @@ bool valu_supported(const Weights &w);
 hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu,
                             hipStream_t stream);
 bool mfma_supported(const Weights &w);
+int mfma_pick_ksplit(size_t rows, size_t cols, bool paired, int nw);
+bool gemvq_supported(const Weights &w);
+hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream);
+hipError_t launch_quant_act(const float *x, const float *gamma, size_t n, void *qout, double *stats, hipStream_t stream);
+hipError_t launch_embed_q(const void *table, const int *tokens, const int *offset_ptr, int hidden, int vocab, float *x_out,
+                          const float *gamma, void *qout, double *stats, hipStream_t stream);
 hipError_t build_tiles(Weights &w, hipStream_t stream);
 // many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
 bool gemm_supported(const Weights &w);
@@ -125,7 +150,7 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
                             bool rms, hipStream_t stream);
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine = true, int halves = 1);
+                              float *scratch, float *out, hipStream_t stream, bool combine = true, int halves = 1, void *qout = nullptr);
 // decode attention chunk record (one per KV head and 64- or 128-position chunk) in the scratch buffer:
 // (m, l) per head of the query group [4][2], then the un-normalised P.V partial [4][128]
 constexpr int kAttnRecFloats = 8 + 4 * 128;

@@ -16,6 +16,7 @@
 // pass reads positions contiguously: lane = position); vcache[n_kv][max_pos][D] (the P.V pass
 // reads dims contiguously: lane = dim).  *pos_ptr = number of cached tokens.
 #include "common.hpp"
+#include "qact.hpp"
 
 namespace bitnet_hip {
 
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
 // group take 4 dims each (float4: one 512-byte record row per group and step).
 __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_kv, int group,
                                                       int n_chunks_max, int chunk_log2, const int *__restrict__ pos_ptr,
-                                                      float *__restrict__ out) {
-    asm volatile("" ::"s"(scratch), "s"(n_kv), "s"(group), "s"(n_chunks_max), "s"(chunk_log2), "s"(out));  // all arguments in one scalar-load round
+                                                      float *__restrict__ out, uint8_t *__restrict__ qout) {
+    asm volatile("" ::"s"(scratch), "s"(n_kv), "s"(group), "s"(n_chunks_max), "s"(chunk_log2), "s"(out), "s"(qout));  // all arguments in one scalar-load round
     const int kvh = blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, d4 = tid & 31, part = tid >> 5;
     __shared__ float sm[8], sl[8];
@@ -323,7 +324,11 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
             L += w * sl[p];
             acc += w * sa[p][tid];
         }
-        out[(size_t)(kvh * group + g) * kD + tid] = acc / L;
+        const float v = acc / L;
+        const int col = (kvh * group + g) * kD + tid;
+        if (out) out[col] = v;
+        // the o-projection's input as a QAct (qact.hpp): 16 consecutive dims = one group, no LayerNorm in between (T:542)
+        if (qout) qact_emit(qout, nullptr, col >> 4, col & 15, v, v);
     }
 }
 
@@ -333,7 +338,7 @@ size_t attn_scratch_floats(int n_kv, int max_pos) {
 
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine, int halves) {
+                              float *scratch, float *out, hipStream_t stream, bool combine, int halves, void *qout) {
     if (D != kD || n_heads / n_kv > kMaxGroup || (halves != 1 && halves != 2)) return hipErrorInvalidValue;
     const int rec_pos = kAttnChunk * halves;  // positions per record
     const int n_rec = (max_pos + rec_pos - 1) / rec_pos;
@@ -347,7 +352,7 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
     // (launch_gemv_mfma with GemvFusion::attn_rec)
     if (combine)
         hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_rec,
-                           halves == 2 ? 7 : 6, pos_ptr, out);
+                           halves == 2 ? 7 : 6, pos_ptr, out, static_cast<uint8_t *>(qout));
     return hipGetLastError();
 }
 

@@ -1,0 +1,360 @@
+// kernels_gemvq.hip -- the I2_S / QK256 GEMV of the decode step on PRE-QUANTISED activations (qact.hpp).
+//
+// Same matrix-core formulation as k_gemv_mfma (kernels_mfma.hip: the vector ALUs only expand 2-bit codes to int8,
+// v_mfma_i32_16x16x64_i8 does every multiply-add), with the three fixed costs round 1's profile charged to every
+// wave removed (VERDICT r1 "what's weak" 5: ~650 VALU instructions per wave, 218 of them quantising activations,
+// 120 LayerNorm statistics; 176 KB of loads per workgroup through a 64 B/clk vector-memory path):
+//
+//  * activations arrive as int8 digit planes + one power-of-two scale per 16 elements, written by the PRODUCING
+//    kernel's epilogue (the previous GEMV, the attention combine, the embedding gather).  A wave copies its K range
+//    (576 B per 256 columns) into LDS with two or three flat 16-byte loads -- no conversion, no row maximum;
+//  * LayerNorm (applied after the product, bitnet_hip_weights_bind_ln) takes its row statistics from one
+//    (sum, sum of squares) pair per producer tile instead of re-reading the row in every wave;
+//  * the MFMA operands are swapped: the WEIGHTS are the B operand (16 output rows = the 16 columns of D), the
+//    activations the A operand, whose 16 rows are (k-group kg, digit d, block half h) selectors -- row 4 kg + 2 d + h
+//    holds digit plane d for the lanes of k-group kg in the MFMAs of parity h and zeros elsewhere.  One lane of D
+//    then holds, for ONE weight row and ONE 32-weight block, the four exact integer sums (d, h) in its four
+//    accumulator registers: digits recombine in integer arithmetic (v_lshl_add_u32), and the 32-block's weight scale
+//    is applied once per lane: 7 VALU instructions per 32-block and lane instead of 12, one f16 scale load per
+//    (row, block) instead of four.
+//
+// Per 1-KiB weight tile (16 rows x 256 columns) a wave issues 4 MFMAs, 44 VALU for the code expansion, 14 for
+// digits + scales, 5 LDS reads.  Numerics: every 16-element partial sum is an exact integer; the activation is
+// held to 2^-15 of its 16-group's maximum (qact.hpp); f32 accumulation in a fixed order (bit-reproducible).
+// Reference semantics: Q/i2s_qk256.rs:196-274 (QK256), K/cpu/quantized_matmul.rs:57-96 (ternary x block scale),
+// T:67-100 (LayerNorm), T:756-781 (silu(gate) * up), T:1073 / T:1125 (residual).
+#include <mutex>
+#include <unordered_set>
+
+#include "common.hpp"
+#include "qact.hpp"
+
+namespace bitnet_hip {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t umin32q(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ v4u ldq_nt16(const void *p) { return __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p)); }
+__device__ __forceinline__ v4i decode16q(uint32_t w, uint32_t lut) {
+    v4i a;
+    a[0] = (int)__builtin_amdgcn_perm(0u, lut, w & 0x03030303u);
+    a[1] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 2) & 0x03030303u);
+    a[2] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 4) & 0x03030303u);
+    a[3] = (int)__builtin_amdgcn_perm(0u, lut, (w >> 6) & 0x03030303u);
+    return a;
+}
+__device__ __forceinline__ float fmix_lo(float a, uint32_t h, float c) {  // a * f16(h.lo) + c
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fmix_hi(float a, uint32_t h, float c) {  // a * f16(h.hi) + c
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double wdpp_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_dq(double v) {
+    v += wdpp_d<0xB1>(v);
+    v += wdpp_d<0x4E>(v);
+    v += wdpp_d<0x141>(v);
+    v += wdpp_d<0x140>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * i);
+        r[i] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+struct GemvQArgs {
+    const uint8_t *tiles;    // [n_tiles][nblk][64 lanes][16 B] code tiles (k_retile)
+    const void *stiles;      // [n_tiles][nblk][64 lanes] x {f16 x 2 | f32 x 2}: 32-block scales (k_retile_scales[_h]) or null
+    int rows, cols, nblk;
+    uint32_t lut;
+    int ks_log2;             // K ranges per row tile = waves sharing a tile
+    const uint8_t *qin;      // QAct records [nblk][576]
+    const double *stats_in;  // LN: (sum, sum of squares) per 16 columns
+    int n_stats;
+    const float *ln_g;       // LN: g_r = W[r,:] . gamma (bitnet_hip_weights_bind_ln)
+    float ln_eps;
+    double inv_cols;
+    const float *residual;   // optional: v = residual + W x
+    float *y;                // optional f32 output
+    int silu_mul;            // rows are (gate tile, up tile) pairs: v = silu(gate) * up
+    uint8_t *qout;           // optional QAct output (for the next GEMV)
+    const float *gamma_out;  // optional: the next GEMV's LayerNorm weight (u = v * gamma)
+    double *stats_out;       // optional: (sum, sum of squares) per 16 output rows
+};
+
+// NW waves per workgroup; RING = 256-column blocks per wave, all in flight at once; SC = weight scales per 32-block:
+// 0 none (QK256), 1 f32, 2 f16; NS = LayerNorm statistics pairs per lane (0 = no LayerNorm).
+// Every global load is unconditional and sits ahead of one scheduling fence (kernels_mfma.hip explains why).
+template <int NW, int RING, int SC, int NS>
+__global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
+    constexpr int NQ = (RING * kQRec + 1023) / 1024;  // 1-KiB flat copies covering this wave's QAct range
+    constexpr int WQ = NQ * 1024;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t *wq = lds + wave * 2 * WQ;  // this wave's copy of its QAct records ...
+    uint8_t *zq = wq + WQ;              // ... and as many zero bytes: what the dead A lanes read (no masking instructions)
+    float *part = reinterpret_cast<float *>(lds + NW * 2 * WQ);  // [NW][64] partial sums by K part
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) *reinterpret_cast<v4u *>(zq + 1024 * i + 16 * lane) = v4u{0u, 0u, 0u, 0u};
+
+    // ---- wave -> (row tile, K range of at most RING blocks), as k_gemv_mfma ------------------------------------
+    const int ksplit = 1 << p.ks_log2;
+    const int tiles_per_wg = NW >> p.ks_log2;
+    const int n_tiles = p.rows >> 4;  // rows % 16 == 0 (launcher)
+    int tile = blockIdx.x * tiles_per_wg + (wave >> p.ks_log2);
+    tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
+    int kpart = wave & (ksplit - 1);
+    if (p.ks_log2 == 3 && wave >= 4) kpart = 11 - wave;  // at most one long range per SIMD (kernels_mfma.hip)
+    const int b0 = (kpart * p.nblk) >> p.ks_log2, b1 = ((kpart + 1) * p.nblk) >> p.ks_log2;
+
+    // ---- 1. this wave's QAct range (L2-resident, shared by every workgroup), then the statistics pairs -------
+    const uint32_t q_last = (uint32_t)kQRec * (uint32_t)p.nblk - 16u, qo0 = (uint32_t)kQRec * (uint32_t)b0 + 16u * (uint32_t)lane;
+    v4u qa[NQ];  // native vectors: arrays of HIP's uint4 struct went through scratch memory at the scheduling fence
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) qa[i] = *reinterpret_cast<const v4u *>(p.qin + umin32q(qo0 + 1024u * i, q_last));
+    v4u st[NS ? NS : 1];  // (sum, sum of squares) f64 pairs, kept as raw dwords until the epilogue
+    if (NS) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = lane + 64 * i;
+            st[i] = *reinterpret_cast<const v4u *>(p.stats_in + 2 * (size_t)(idx < p.n_stats ? idx : p.n_stats - 1));
+        }
+    }
+    // vmcnt retires in order: the activations must be REQUESTED ahead of the weight stream, or their arrival only
+    // counts once every weight tile has landed
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. weight tiles (+ their scale tiles): read once by this wave only -> non-temporal -------------------
+    const size_t tb0 = (size_t)tile * p.nblk;
+    const uint8_t *wbase = p.tiles + (tb0 * 64 + lane) * 16;
+    v4u wt[RING];
+    uint32_t sh[SC == 2 ? RING : 1];
+    float2 sf[SC == 1 ? RING : 1];
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+        const int blk = b0 + j < b1 ? b0 + j : b1 - 1;  // clamped: a short range re-reads its last tile
+        wt[j] = ldq_nt16(wbase + (size_t)blk * 1024);
+        if (SC == 2) sh[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.stiles) + (tb0 + blk) * 64 + lane);
+        if (SC == 1) {
+            const float *sp = reinterpret_cast<const float *>(p.stiles) + ((tb0 + blk) * 64 + lane) * 2;
+            sf[j] = float2{__builtin_nontemporal_load(sp), __builtin_nontemporal_load(sp + 1)};
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load of this wave is requested before anything waits
+
+    // ---- 3. QAct records -> LDS (this wave's own region: LDS executes a wave's accesses in order) --------------
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) *reinterpret_cast<v4u *>(wq + 1024 * i + 16 * lane) = qa[i];
+
+    // A-operand lane (k-group g, selector row c = 4 kg + 2 d + h): digit plane d of k-group kg, live in the MFMAs
+    // of parity h only; every other (lane, MFMA) reads zeros.  D lane (g, c): selector group g, weight row c.
+    const int g = lane >> 4, c = lane & 15;
+    const bool mine = (c >> 2) == g;
+    const uint8_t *live = wq + 256 * ((c >> 1) & 1) + 64 * g;
+    const uint8_t *ba0 = (mine && (c & 1) == 0) ? live : zq;  // MFMAs 0 and 2 of a block
+    const uint8_t *ba1 = (mine && (c & 1) == 1) ? live : zq;  // MFMAs 1 and 3
+    const uint8_t *sa = wq + 512 + 16 * g;                    // this lane's four group scales of a record
+
+    float facc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+        if (j > 0 && b0 + j >= b1) continue;  // wave-uniform: a slot past this wave's range
+        const float4 as = *reinterpret_cast<const float4 *>(sa + kQRec * j);  // (h0 p0, h0 p1, h1 p0, h1 p1)
+        const uint32_t wd[4] = {wt[j][0], wt[j][1], wt[j][2], wt[j][3]};
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {  // the lane group's two 32-weight blocks
+            v4i acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i *>(ba0 + kQRec * j + 32 * pp),
+                                                        decode16q(wd[2 * pp], p.lut), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i *>(ba1 + kQRec * j + 32 * pp + 16),
+                                                        decode16q(wd[2 * pp + 1], p.lut), acc, 0, 0, 0);
+            // acc[2 d + h]: exact sums over the 16 weights of half h with digit plane d; |.| <= 16 * 2 * 128
+            const int i0 = (int)(((uint32_t)acc[2] << 8) + (uint32_t)acc[0]), i1 = (int)(((uint32_t)acc[3] << 8) + (uint32_t)acc[1]);
+            float t = (float)i0 * (pp ? as.y : as.x);
+            t = fmaf((float)i1, pp ? as.w : as.z, t);
+            if (SC == 2)
+                facc = pp ? fmix_hi(t, sh[j], facc) : fmix_lo(t, sh[j], facc);
+            else if (SC == 1)
+                facc = fmaf(t, pp ? sf[j].y : sf[j].x, facc);
+            else
+                facc += t;
+        }
+    }
+    part[(((wave >> p.ks_log2) << p.ks_log2) + kpart) * 64 + lane] = facc;
+
+    // ---- 4. epilogue: the storing waves only ------------------------------------------------------------------
+    const bool storing = wave * 64 < tiles_per_wg * 16;
+    double ln_mean = 0.0, ln_rdenom = 1.0;
+    if (NS && storing) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const bool in = lane + 64 * i < p.n_stats;
+            const double a = __builtin_bit_cast(double, ((unsigned long long)st[i][1] << 32) | st[i][0]);
+            const double b = __builtin_bit_cast(double, ((unsigned long long)st[i][3] << 32) | st[i][2]);
+            s1 += in ? a : 0.0;
+            s2 += in ? b : 0.0;
+        }
+        s1 = wave_sum_dq(s1);
+        s2 = wave_sum_dq(s2);
+        const double mean_d = s1 * p.inv_cols;
+        const double var_d = s2 * p.inv_cols - mean_d * mean_d;
+        ln_mean = (double)(float)mean_d;  // the f32 mean the reference subtracts
+        const double denom = (double)sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+        double r = __builtin_amdgcn_rcp(denom);
+        r = r * (2.0 - denom * r);
+        ln_rdenom = r * (2.0 - denom * r);
+    }
+    __syncthreads();
+    if (!storing) return;
+    const int tl = tid >> 4, r = tid & 15;
+    if (!p.silu_mul) {
+        if (tl >= tiles_per_wg) return;
+        const int t_glob = blockIdx.x * tiles_per_wg + tl;
+        if (t_glob >= n_tiles) return;  // whole 16-lane rows leave together
+        const int row = 16 * t_glob + r;
+        float v = 0.0f;
+        for (int kp = 0; kp < ksplit; ++kp) {
+            const float *pp = part + ((tl << p.ks_log2) + kp) * 64 + r;
+            v += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+        }
+        if (NS) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) * ln_rdenom);
+        if (p.residual) v += p.residual[row];
+        if (p.y) p.y[row] = v;
+        if (p.qout) qact_emit(p.qout, p.stats_out, t_glob, r, v, p.gamma_out ? v * p.gamma_out[row] : v);
+    } else {
+        const int pairs_per_wg = tiles_per_wg >> 1;
+        if (tl >= pairs_per_wg) return;
+        const int p_glob = blockIdx.x * pairs_per_wg + tl;
+        if (2 * p_glob >= n_tiles) return;
+        const int row = 16 * p_glob + r;  // row of silu(gate) * up
+        float gv = 0.0f, uv = 0.0f;
+        for (int kp = 0; kp < ksplit; ++kp) {
+            const float *pg = part + (((2 * tl) << p.ks_log2) + kp) * 64 + r, *pu = part + (((2 * tl + 1) << p.ks_log2) + kp) * 64 + r;
+            gv += (pg[0] + pg[16]) + (pg[32] + pg[48]);
+            uv += (pu[0] + pu[16]) + (pu[32] + pu[48]);
+        }
+        if (NS) {  // stored rows of the paired matrix: (gate tile, up tile)
+            gv = (float)(((double)gv - ln_mean * (double)p.ln_g[32 * p_glob + r]) * ln_rdenom);
+            uv = (float)(((double)uv - ln_mean * (double)p.ln_g[32 * p_glob + 16 + r]) * ln_rdenom);
+        }
+        const float v = gv / (1.0f + expf(-gv)) * uv;  // FeedForward::forward T:756-781
+        if (p.y) p.y[row] = v;
+        if (p.qout) qact_emit(p.qout, p.stats_out, p_glob, r, v, p.gamma_out ? v * p.gamma_out[row] : v);
+    }
+}
+
+// ---- standalone producers: any f32 vector -> QAct (tests, the first layer's input) ----------------------------
+__global__ __launch_bounds__(256) void k_quant_act(const float *__restrict__ x, const float *__restrict__ gamma, int n,
+                                                   uint8_t *__restrict__ qout, double *__restrict__ stats) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // n % 16 == 0: whole 16-lane rows are in or out together
+    if (i >= n) return;
+    const float v = x[i];
+    qact_emit(qout, stats, i >> 4, i & 15, v, gamma ? v * gamma[i] : v);
+}
+
+// TransformerModel::embed (T:1390-1426) of ONE token + the first block's QAct (its attention_norm gamma)
+__global__ __launch_bounds__(256) void k_embed_q(const _Float16 *__restrict__ table, const int *__restrict__ tokens,
+                                                 const int *__restrict__ offset_ptr, int hidden, int vocab, float *__restrict__ x_out,
+                                                 const float *__restrict__ gamma, uint8_t *__restrict__ qout, double *__restrict__ stats) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hidden) return;
+    int tok = tokens[offset_ptr ? *offset_ptr : 0];
+    tok = tok < 0 ? 0 : tok >= vocab ? vocab - 1 : tok;  // ids are range-checked on the host (Decoder::feed); never a wild read
+    const float v = (float)table[(size_t)tok * hidden + i];
+    x_out[i] = v;
+    qact_emit(qout, stats, i >> 4, i & 15, v, gamma ? v * gamma[i] : v);
+}
+
+}  // namespace
+
+bool gemvq_supported(const Weights &w) {
+    if (!mfma_supported(w)) return false;
+    if (w.cols % 256 != 0 || w.rows % 16 != 0) return false;   // whole records, whole producer tiles
+    if (w.scales && w.block_size != 32) return false;          // 256-block scales stay on k_gemv_mfma
+    return true;
+}
+
+hipError_t launch_quant_act(const float *x, const float *gamma, size_t n, void *qout, double *stats, hipStream_t stream) {
+    if (n == 0 || n % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_quant_act, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, stream, x, gamma, (int)n, static_cast<uint8_t *>(qout), stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_q(const void *table, const int *tokens, const int *offset_ptr, int hidden, int vocab, float *x_out,
+                          const float *gamma, void *qout, double *stats, hipStream_t stream) {
+    if (hidden <= 0 || hidden % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_embed_q, dim3((unsigned)div_ceil((size_t)hidden, 256)), dim3(256), 0, stream, static_cast<const _Float16 *>(table), tokens,
+                       offset_ptr, hidden, vocab, x_out, gamma, static_cast<uint8_t *>(qout), stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream) {
+    if (!w.tiles || !gemvq_supported(w)) return hipErrorInvalidValue;
+    const bool sc_any = w.scales != nullptr;
+    const int sc = !sc_any ? 0 : w.scales_f16 ? 2 : 1;
+    if (sc == 2 && !w.scale_tiles_h) return hipErrorInvalidValue;
+    if (sc == 1 && !w.scale_tiles) return hipErrorInvalidValue;
+    GemvQArgs a;
+    a.tiles = w.tiles;
+    a.stiles = sc == 2 ? (const void *)w.scale_tiles_h : sc == 1 ? (const void *)w.scale_tiles : nullptr;
+    a.rows = (int)w.rows;
+    a.cols = (int)w.cols;
+    a.nblk = (int)(w.cols / 256);
+    a.lut = w.lut;
+    const int nw = 8;
+    const int ksplit = mfma_pick_ksplit(w.rows, w.cols, io.silu_mul, nw);
+    a.ks_log2 = ksplit == 8 ? 3 : ksplit == 4 ? 2 : ksplit == 2 ? 1 : 0;
+    a.qin = static_cast<const uint8_t *>(io.qin);
+    const bool ln = io.ln_gamma != nullptr;
+    if (ln && !(w.ln_g && w.ln_gamma_bound == io.ln_gamma && io.stats_in)) return hipErrorInvalidValue;  // LayerNorm only in the after-product form
+    a.stats_in = io.stats_in;
+    a.n_stats = (int)(w.cols / 16);
+    a.ln_g = w.ln_g;
+    a.ln_eps = io.ln_eps;
+    a.inv_cols = 1.0 / (double)w.cols;
+    a.residual = io.residual;
+    a.y = io.y;
+    a.silu_mul = io.silu_mul ? 1 : 0;
+    a.qout = static_cast<uint8_t *>(io.qout);
+    a.gamma_out = io.gamma_out;
+    a.stats_out = io.stats_out;
+    if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
+    const int tiles_per_wg = nw / ksplit;
+    const unsigned grid = (unsigned)div_ceil(w.rows / 16, (size_t)tiles_per_wg);
+    const int ring = (int)div_ceil((size_t)a.nblk, (size_t)ksplit);
+    const int ns = !ln ? 0 : a.n_stats <= 192 ? 3 : a.n_stats <= 256 ? 4 : -1;
+    if (ring > 5 || ns < 0) return hipErrorInvalidValue;
+    void (*kfn)(GemvQArgs) = nullptr;
+#define BH_QPICK(RINGv)                                                                                                             \
+    if (!kfn && ring <= RINGv)                                                                                                      \
+        kfn = ns == 0 ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 0> : sc == 1 ? k_gemv_q<8, RINGv, 1, 0> : k_gemv_q<8, RINGv, 0, 0>)         \
+              : ns == 3 ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 3> : sc == 1 ? k_gemv_q<8, RINGv, 1, 3> : k_gemv_q<8, RINGv, 0, 3>)       \
+                        : (sc == 2 ? k_gemv_q<8, RINGv, 2, 4> : sc == 1 ? k_gemv_q<8, RINGv, 1, 4> : k_gemv_q<8, RINGv, 0, 4>);
+    BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
+#undef BH_QPICK
+    if (!kfn) return hipErrorInvalidValue;
+    const int ring_t = ring <= 2 ? 2 : ring;
+    const size_t lds = (size_t)nw * 2 * (((size_t)ring_t * kQRec + 1023) / 1024 * 1024) + (size_t)nw * 64 * sizeof(float);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace bitnet_hip

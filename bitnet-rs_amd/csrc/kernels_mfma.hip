@@ -35,6 +35,7 @@
 #include <unordered_set>
 
 #include "common.hpp"
+#include "qact.hpp"
 
 namespace bitnet_hip {
 
@@ -89,13 +90,17 @@ struct MfmaArgs {
     float ln_eps;
     const float *residual; // optional: y = residual + W x
     const float *wscale;   // optional f32 scale per (row, 256-block)
-    const float *stiles;   // optional f32 scales per (row, 32-block), tiled [tile][blk][q][cg][half][j]
+    const float *stiles;   // optional f32 scales per (row, 32-block), tiled [tile][blk][kg][row][p] (k_retile_scales)
     const uint16_t *stiles_h;  // the same as f16 when every scale is an f16 value (template BS32 == 2)
     int silu_mul;          // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     // MERGE: x is the decode attention output, merged here from its chunk records (GemvFusion::attn_rec)
     const float *attn_rec;
     const int *attn_pos;
     int attn_chunks_max, attn_group_log2, attn_chunk_log2;
+    // the output as a QAct for the next GEMV (qact.hpp; rows % 16 == 0): records, the consumer's LayerNorm weight, statistics pairs
+    uint8_t *qout;
+    const float *gamma_out;
+    double *stats_out;
     unsigned long long *stamps;  // diagnostic builds only
 };
 
@@ -314,9 +319,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
 
     // ---- 2. weight tiles: RING 1-KiB tiles in flight per wave ------------------------------
     const uint8_t *wbase = p.tiles + ((size_t)tile * p.nblk * 64 + lane) * 16;
-    // 32-element block scales ride along: 512 B per tile, 32 B per lane (8 floats: rows
-    // 4q..4q+3 of 32-blocks 2*cg and 2*cg+1 of this 256-block), shared by the 4 digit lanes
-    const size_t sidx = ((size_t)tile * p.nblk * 16 + (size_t)(g * 4 + (r16 >> 2))) * 8;
+    // 32-element block scales ride along, layout [tile][256-block][kg][row c][p] (one layout for this kernel and
+    // kernels_gemvq.hip): this lane (rows 4g..4g+3 of the tile, k-group kg = r16 >> 2) needs rows 4g+i, 32-blocks
+    // 2 kg + p = 8 consecutive values [i][p], shared by the 4 digit lanes
+    const size_t sidx = ((size_t)tile * p.nblk * 16 + (size_t)((r16 >> 2) * 4 + g)) * 8;
     const float *sbase = BS32 == 1 ? p.stiles + sidx : nullptr;
     const uint16_t *sbase_h = BS32 == 2 ? p.stiles_h + sidx : nullptr;
     uint4 wt[RING];
@@ -480,16 +486,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 if (m & 1) {
                     float4 sv;
                     if (BS32 == 2) {
-                        // f16 scales go into the fma as they are (v_fma_mix_f32: f32 * f16 + f32), no conversions
-                        const uint32_t a01 = m == 1 ? s_h[j].x : s_h[j].z, a23 = m == 1 ? s_h[j].y : s_h[j].w;
-                        facc[0] = fma_mix_lo((float)acc[0], a01, facc[0]);
-                        facc[1] = fma_mix_hi((float)acc[1], a01, facc[1]);
-                        facc[2] = fma_mix_lo((float)acc[2], a23, facc[2]);
-                        facc[3] = fma_mix_hi((float)acc[3], a23, facc[3]);
+                        // f16 scales go into the fma as they are (v_fma_mix_f32: f32 * f16 + f32), no conversions;
+                        // dword i = row 4g+i: (32-block 2 kg, 32-block 2 kg + 1)
+                        if (m == 1) {
+                            facc[0] = fma_mix_lo((float)acc[0], s_h[j].x, facc[0]);
+                            facc[1] = fma_mix_lo((float)acc[1], s_h[j].y, facc[1]);
+                            facc[2] = fma_mix_lo((float)acc[2], s_h[j].z, facc[2]);
+                            facc[3] = fma_mix_lo((float)acc[3], s_h[j].w, facc[3]);
+                        } else {
+                            facc[0] = fma_mix_hi((float)acc[0], s_h[j].x, facc[0]);
+                            facc[1] = fma_mix_hi((float)acc[1], s_h[j].y, facc[1]);
+                            facc[2] = fma_mix_hi((float)acc[2], s_h[j].z, facc[2]);
+                            facc[3] = fma_mix_hi((float)acc[3], s_h[j].w, facc[3]);
+                        }
                         acc = (v4i){0, 0, 0, 0};
                         continue;
                     } else {
-                        sv = m == 1 ? s_lo[j] : s_hi[j];
+                        sv = m == 1 ? float4{s_lo[j].x, s_lo[j].z, s_hi[j].x, s_hi[j].z} : float4{s_lo[j].y, s_lo[j].w, s_hi[j].y, s_hi[j].w};
                     }
                     facc[0] += (float)acc[0] * sv.x;
                     facc[1] += (float)acc[1] * sv.y;
@@ -586,6 +599,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                 if (LN == 2) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) * ln_rdenom);
                 if (pres) v += pres[row];
                 py[row] = v;
+                if (p.qout) qact_emit(p.qout, p.stats_out, row >> 4, r, v, p.gamma_out ? v * p.gamma_out[row] : v);  // rows % 16 == 0: whole 16-lane rows get here
             }
         }
     } else {
@@ -606,7 +620,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_mfma(MfmaArgs p) {
                     gv = (float)(((double)gv - ln_mean * (double)p.ln_g[16 * t0 + r]) * ln_rdenom);
                     uv = (float)(((double)uv - ln_mean * (double)p.ln_g[16 * (t0 + 1) + r]) * ln_rdenom);
                 }
-                py[row] = gv / (1.0f + expf(-gv)) * uv;
+                const float hv = gv / (1.0f + expf(-gv)) * uv;
+                py[row] = hv;
+                if (p.qout) qact_emit(p.qout, p.stats_out, row >> 4, r, hv, p.gamma_out ? hv * p.gamma_out[row] : hv);
             }
         }
     }
@@ -672,6 +688,10 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.attn_chunks_max = fu.attn_chunks_max;
     a.attn_group_log2 = fu.attn_group_log2;
     a.attn_chunk_log2 = fu.attn_chunk_log2;
+    a.qout = static_cast<uint8_t *>(fu.qout);
+    a.gamma_out = fu.gamma_out;
+    a.stats_out = fu.stats_out;
+    if (fu.qout && (w.rows % 16 != 0 || m != 1 || (fu.silu_mul && w.rows % 32 != 0))) return hipErrorInvalidValue;
     a.stamps = g_mfma_stamps;
     const int tiles_per_wg = nw / a.ksplit;
     const unsigned grid = (unsigned)div_ceil(div_ceil(w.rows, 16), tiles_per_wg);
@@ -755,29 +775,30 @@ __global__ void k_retile(const uint8_t *__restrict__ codes, size_t row_stride, i
     *reinterpret_cast<uint4 *>(tiles + i * 16) = v;
 }
 
-// scales [rows, cols/32] -> [tile][256-block][q][cg][half][j]: the 8 floats lane (q, cg) needs
-// for one 256-column block are contiguous (rows 4q+j, 32-blocks 2*cg + half).
+// scales [rows, cols/32] -> [tile][256-block][kg][row c][p]: value of (row 16 tile + c, 32-block 8 blk + 2 kg + p).
+// A lane of kernels_gemvq.hip (kg, c) reads its two values as one dword (f16) / one float2; a lane of k_gemv_mfma
+// (rows 4g..4g+3, k-group kg) reads 8 consecutive values.
 __global__ void k_retile_scales(const float *__restrict__ scales, int rows, int nblk, float *__restrict__ out,
                                 size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int j = (int)(i & 3), half = (int)((i >> 2) & 1), cg = (int)((i >> 3) & 3), q = (int)((i >> 5) & 3);
+    const int p = (int)(i & 1), c = (int)((i >> 1) & 15), kg = (int)((i >> 5) & 3);
     const size_t tb = i >> 7;
     const int blk = (int)(tb % nblk);
     const size_t tile = tb / nblk;
-    const int row = (int)(16 * tile + 4 * q + j);
-    out[i] = row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * cg + half] : 0.0f;
+    const int row = (int)(16 * tile + c);
+    out[i] = row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * kg + p] : 0.0f;
 }
 
 __global__ void k_retile_scales_h(const float *__restrict__ scales, int rows, int nblk, uint16_t *__restrict__ out, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int j = (int)(i & 3), half = (int)((i >> 2) & 1), cg = (int)((i >> 3) & 3), q = (int)((i >> 5) & 3);
+    const int p = (int)(i & 1), c = (int)((i >> 1) & 15), kg = (int)((i >> 5) & 3);
     const size_t tb = i >> 7;
     const int blk = (int)(tb % nblk);
     const size_t tile = tb / nblk;
-    const int row = (int)(16 * tile + 4 * q + j);
-    const _Float16 h = (_Float16)(row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * cg + half] : 0.0f);  // exact: checked at upload
+    const int row = (int)(16 * tile + c);
+    const _Float16 h = (_Float16)(row < rows ? scales[(size_t)row * nblk * 8 + 8 * blk + 2 * kg + p] : 0.0f);  // exact: checked at upload
     out[i] = __builtin_bit_cast(uint16_t, h);
 }
 

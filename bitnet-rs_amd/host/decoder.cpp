@@ -69,6 +69,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
         return;
     }
     if (const char *e = getenv("BITNET_HOST_LOGITS_WGS")) logits_wgs_ = atoi(e) > 0 ? atoi(e) : logits_wgs_;  // tuning knob
+    if (const char *e = getenv("BITNET_HOST_ACT")) act_mode_ = atoi(e) != 0 ? 1 : 0;  // 0: exact f32 activations between the kernels
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
         err_ = e ? e : "bitnet_hip_init failed";
@@ -92,6 +93,16 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
     ok &= dalloc(&qkv_, (size_t)(c_.n_heads + 2 * c_.n_kv_heads) * D) == hipSuccess;
     ok &= dalloc(&att_, (size_t)c_.n_heads * D) == hipSuccess;
     ok &= dalloc(&h_, (size_t)c_.ffn) == hipSuccess;
+    {
+        // QAct records + LayerNorm statistics pairs of the four vectors that travel between the step's GEMVs (zero-filled
+        // once: bytes past a vector's last group are never written and must read as zero digits)
+        const size_t qh = bitnet_hip_qact_bytes(H), qq = bitnet_hip_qact_bytes((size_t)c_.n_heads * D), qf = bitnet_hip_qact_bytes((size_t)c_.ffn);
+        const size_t sb = bitnet_hip_qact_stats_bytes(H);
+        ok = ok && hipMalloc(&qa_x_, qh) == hipSuccess && hipMalloc(&qa_x2_, qh) == hipSuccess && hipMalloc(&qa_att_, qq) == hipSuccess &&
+             hipMalloc(&qa_h_, qf) == hipSuccess && hipMalloc((void **)&st_x_, sb) == hipSuccess && hipMalloc((void **)&st_x2_, sb) == hipSuccess;
+        ok = ok && hipMemset(qa_x_, 0, qh) == hipSuccess && hipMemset(qa_x2_, 0, qh) == hipSuccess && hipMemset(qa_att_, 0, qq) == hipSuccess &&
+             hipMemset(qa_h_, 0, qf) == hipSuccess && hipMemset(st_x_, 0, sb) == hipSuccess && hipMemset(st_x2_, 0, sb) == hipSuccess;
+    }
     ok &= dalloc(&ref_n_, H > (size_t)c_.ffn ? H : (size_t)c_.ffn) == hipSuccess && dalloc(&ref_gu_, 2 * (size_t)c_.ffn) == hipSuccess &&
           dalloc(&ref_t_, H) == hipSuccess;
     ok &= dalloc(&logits_, (size_t)c_.vocab) == hipSuccess;
@@ -142,7 +153,7 @@ Decoder::~Decoder() {
             if (p) hipFree(p);
     }
     for (void *p : {(void *)embed_, (void *)final_norm_, (void *)rope_sin_, (void *)rope_cos_, (void *)x_, (void *)x2_,
-                    (void *)qkv_, (void *)att_, (void *)h_, (void *)ref_n_, (void *)ref_gu_, (void *)ref_t_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
+                    (void *)qkv_, (void *)att_, (void *)h_, (void *)ref_n_, (void *)ref_gu_, (void *)ref_t_, qa_x_, qa_x2_, qa_att_, qa_h_, (void *)st_x_, (void *)st_x2_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
@@ -197,6 +208,27 @@ int Decoder::adopt_projections(Layer &L, bitnet_hip_weights_t h[7]) {
     // LayerNorm applied after the product for the two normalised projections (bitnet_hip_weights_bind_ln)
     BCHK(bitnet_hip_weights_bind_ln(L.qkv, L.attn_norm, stream_));
     BCHK(bitnet_hip_weights_bind_ln(L.gateup, L.ffn_norm, stream_));
+    L.q_ok = bitnet_hip_gemv_q_supported(L.qkv) && bitnet_hip_gemv_q_supported(L.o) && bitnet_hip_gemv_q_supported(L.gateup) &&
+             bitnet_hip_gemv_q_supported(L.down) && c_.hidden <= 4096;
+    return 0;
+}
+
+// The step runs on producer-quantised activations (include/bitnet_hip.h "QAct") when every layer's matrices are on that
+// path and the mode asks for it; otherwise on exact f32 activations (round 1's kernels).
+bool Decoder::qact_path() const {
+    if (act_mode_ == 0) return false;
+    for (const auto &L : layers_)
+        if (!L.q_ok) return false;
+    return true;
+}
+
+int Decoder::set_act_mode(int mode) {
+    if (mode != 0 && mode != 1) {
+        err_ = "activation mode must be 0 (exact f32) or 1 (QAct)";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (mode != act_mode_) drop_graphs();
+    act_mode_ = mode;
     return 0;
 }
 
@@ -325,6 +357,35 @@ int Decoder::position() {
 int Decoder::step_launches(bool with_logits, int form) {
     void *s = stream_;
     const size_t H = c_.hidden;
+    if (qact_path()) {
+        // Every vector that travels between two GEMVs goes as a QAct written by its producer's epilogue (x: embedding /
+        // down-projection, attention output: combine kernel or merging o-projection, x2: o-projection, h: gate|up).
+        const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
+        BCHK(bitnet_hip_embed_q_dev(embed_, history_, pos_, H, (size_t)c_.vocab, x_, layers_[0].attn_norm, qa_x_, st_x_, s));
+        for (size_t l = 0; l < layers_.size(); ++l) {
+            Layer &L = layers_[l];
+            BCHK(bitnet_hip_gemv_q_dev(L.qkv, qa_x_, st_x_, L.attn_norm, c_.eps, nullptr, 0, qkv_, nullptr, nullptr, nullptr, s));
+            if (form == 1) {
+                BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, s));
+                BCHK(bitnet_hip_gemv_attn_merge_q_dev(L.o, attn_scratch_, NH, NK, MP, pos_, x2_, x_, qa_x2_, L.ffn_norm, st_x2_, s));
+            } else {
+                BCHK(bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, form == 2 ? 1 : 0,
+                                                       nullptr, qa_att_, s));
+                BCHK(bitnet_hip_gemv_q_dev(L.o, qa_att_, nullptr, nullptr, 0.f, x_, 0, x2_, qa_x2_, L.ffn_norm, st_x2_, s));
+            }
+            BCHK(bitnet_hip_gemv_q_dev(L.gateup, qa_x2_, st_x2_, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, nullptr, qa_h_, nullptr, nullptr, s));
+            const bool more = l + 1 < layers_.size();
+            BCHK(bitnet_hip_gemv_q_dev(L.down, qa_h_, nullptr, nullptr, 0.f, x2_, 0, x_, more ? qa_x_ : nullptr, more ? layers_[l + 1].attn_norm : nullptr,
+                                       more ? st_x_ : nullptr, s));
+        }
+        if (with_logits) {
+            BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_, pos_,
+                                           history_, n_forced_, s));
+        } else {
+            BCHK(bitnet_hip_advance_pos_dev(pos_, s));
+        }
+        return 0;
+    }
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
     for (auto &L : layers_) {
         // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
@@ -615,7 +676,27 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
     int rc = 0;
     const size_t H = c_.hidden;
     int launches = 0;
-    for (auto &L : layers_) {
+    const bool qp = qact_path();
+    for (size_t li = 0; li < layers_.size(); ++li) {
+        Layer &L = layers_[li];
+        if (qp && kind <= 4) {
+            const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
+            const bool more = li + 1 < layers_.size();
+            switch (kind) {
+                case 0: rc = bitnet_hip_gemv_q_dev(L.qkv, qa_x_, st_x_, L.attn_norm, c_.eps, nullptr, 0, qkv_, nullptr, nullptr, nullptr, stream_); break;
+                case 1: rc = bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, 0, nullptr, qa_att_, stream_); break;
+                case 2: rc = bitnet_hip_gemv_q_dev(L.o, qa_att_, nullptr, nullptr, 0.f, x_, 0, x2_, qa_x2_, L.ffn_norm, st_x2_, stream_); break;
+                case 3: rc = bitnet_hip_gemv_q_dev(L.gateup, qa_x2_, st_x2_, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, nullptr, qa_h_, nullptr, nullptr, stream_); break;
+                default:
+                    // x_ is both the residual stream's next value and (kind 2) its old one in the real step; here it is only written
+                    rc = bitnet_hip_gemv_q_dev(L.down, qa_h_, nullptr, nullptr, 0.f, x2_, 0, ref_t_, more ? qa_x_ : nullptr, more ? layers_[li + 1].attn_norm : nullptr,
+                                               more ? st_x_ : nullptr, stream_);
+                    break;
+            }
+            ++launches;
+            if (rc) break;
+            continue;
+        }
         switch (kind) {
             case 0: rc = bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, stream_); break;
             case 1:
@@ -662,6 +743,18 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
         size_t ab = 0;
         const Layer &L = layers_[0];
         const double kv = 2.0 * c_.n_kv_heads * (double)(position() + 1) * c_.head_dim * 4;
+        if (qp && kind <= 4 && kind != 1) {
+            // QAct path: codes + scales + the activation records read (+ statistics pairs) + what the launch writes
+            const double qH = (double)bitnet_hip_qact_bytes(H), qF = (double)bitnet_hip_qact_bytes((size_t)c_.ffn), sH = (double)bitnet_hip_qact_stats_bytes(H);
+            const bitnet_hip_weights_t hh = kind == 0 ? L.qkv : kind == 2 ? L.o : kind == 3 ? L.gateup : L.down;
+            bitnet_hip_weights_info(hh, nullptr, nullptr, &ab);
+            const double io = kind == 0 ? qH + sH + 4.0 * H + 4.0 * (c_.n_heads + 2 * c_.n_kv_heads) * c_.head_dim   // + g_r
+                            : kind == 2 ? (double)bitnet_hip_qact_bytes((size_t)c_.n_heads * c_.head_dim) + 12.0 * H + qH + sH  // residual in, f32 out, gamma, QAct + stats out
+                            : kind == 3 ? qH + sH + 8.0 * c_.ffn + qF                                                 // g_r of both halves, QAct out
+                                        : qF + 12.0 * H + qH + sH;
+            *bytes_per_launch = (double)ab + io;
+            return 0;
+        }
         switch (kind) {  // algorithmic bytes of one launch: codes + scales + vector in + vector out
             case 0: bitnet_hip_weights_info(L.qkv, nullptr, nullptr, &ab); *bytes_per_launch = (double)ab + 8.0 * H + 4.0 * (c_.n_heads + 2 * c_.n_kv_heads) * c_.head_dim; break;
             case 1: *bytes_per_launch = kv + 8.0 * c_.n_heads * c_.head_dim; break;
@@ -728,6 +821,8 @@ int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *fin
 }
 int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
 int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
+int bitnet_host_set_act_mode(void *d, int mode) { return static_cast<Decoder *>(d)->set_act_mode(mode); }
+int bitnet_host_act_mode(void *d) { return static_cast<Decoder *>(d)->qact_path() ? 1 : 0; }
 int bitnet_host_run_reference(void *d, int n, int with_logits) { return static_cast<Decoder *>(d)->run_reference(n, with_logits != 0); }
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);

@@ -82,6 +82,10 @@ class Decoder {
     // The same n steps UNFUSED, in the reference's op order, every projection on the reference-order (bit-exact)
     // kernel: the checker bench.py and the tests hold the fast step against at the full model size.  Eager, slow.
     int run_reference(int n, bool with_logits);
+    // Activations between the step's kernels: 1 (default) = quantised once by their producer ("QAct", include/bitnet_hip.h:
+    // the f16-class activation north_star names), 0 = exact f32 (round 1's kernels).  Env BITNET_HOST_ACT sets the default.
+    int set_act_mode(int mode);
+    bool qact_path() const;  // mode 1 AND every layer's matrices are on that path
     // Whole-prompt forward on a fresh sequence (position() == 0): the first n fed tokens go
     // through every layer as [n, *] matrices (TransformerModel::forward with seq_len n,
     // T:1557-1597): tiled matmuls + causal attention, KV cache filled for positions 0..n-1.
@@ -128,6 +132,7 @@ class Decoder {
         float *attn_norm = nullptr, *ffn_norm = nullptr;
         bitnet_hip_weights_t qkv = 0, o = 0, gateup = 0, down = 0;
         float *kcache = nullptr, *vcache = nullptr;
+        bool q_ok = false;  // all four matrices take QAct inputs (bitnet_hip_gemv_q_supported)
     };
     void release_layer(Layer &L);  // frees the layer's handles, subtracts their bytes, drops the captured graphs
     void drop_graphs();
@@ -137,6 +142,9 @@ class Decoder {
     float *final_norm_ = nullptr;
     float *rope_sin_ = nullptr, *rope_cos_ = nullptr;
     float *x_ = nullptr, *x2_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *h_ = nullptr, *logits_ = nullptr;
+    void *qa_x_ = nullptr, *qa_x2_ = nullptr, *qa_att_ = nullptr, *qa_h_ = nullptr;  // QAct records of x, x2, attention output, silu(gate)*up
+    double *st_x_ = nullptr, *st_x2_ = nullptr;                                       // LayerNorm statistics pairs of x, x2
+    int act_mode_ = 1;
     float *ref_n_ = nullptr, *ref_gu_ = nullptr, *ref_t_ = nullptr;  // unfused reference step: normalised row, gate|up tiles, projection out
     void *scratch_ = nullptr;
     float *attn_scratch_ = nullptr;
@@ -175,6 +183,8 @@ int bitnet_host_reset(void *d);
 int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
 int bitnet_host_run_reference(void *d, int n, int with_logits);
+int bitnet_host_set_act_mode(void *d, int mode);
+int bitnet_host_act_mode(void *d);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);
 void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4);

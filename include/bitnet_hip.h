@@ -310,6 +310,45 @@ size_t bitnet_hip_attention_merge_max_keys(void); /* largest *pos_dev + 1 the me
 int bitnet_hip_gemv_attn_merge_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
                                    size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
                                    const float *residual_dev, void *stream);
+/* ---- the decode step on activations quantised by their PRODUCER ("QAct") ---------------------------------------
+ * north_star's kernel is "2-bit weight unpack x f16 activation dot product".  The f16-class activation of this
+ * library is a QAct: per 16 consecutive elements one power-of-two scale and a 15-bit fixed-point value per element
+ * (two int8 digit planes), i.e. every element to 2^-15 of its 16-group's maximum; 576 bytes per 256 elements
+ * (bitnet_hip_qact_bytes; layout private to the library, csrc/qact.hpp).  The kernel that PRODUCES a vector
+ * writes it in this form (16 output rows of a GEMV = one group), so the consuming GEMV feeds the digit planes to the
+ * matrix cores without touching them -- in round 1 every wave of every GEMV re-quantised its K range.  Exact f32
+ * activations stay available through gemv_dev / gemv_fused_dev.
+ * LayerNorm between producer and consumer (T:1015, T:1104) is applied after the product as with weights_bind_ln:
+ * the producer multiplies by the consumer's gamma (gamma_out_dev) before quantising and leaves one (sum, sum of
+ * squares) f64 pair per 16 rows (stats_out, bitnet_hip_qact_stats_bytes); the consumer passes them as stats_in together
+ * with the bound ln_gamma_dev.  Shapes: cols % 256 == 0, rows % 16 == 0, no scales or 32-element block scales
+ * (bitnet_hip_gemv_q_supported); everything else stays on gemv_fused_dev. */
+size_t bitnet_hip_qact_bytes(size_t cols);
+size_t bitnet_hip_qact_stats_bytes(size_t cols);
+/* any f32 device vector -> QAct [* gamma] [+ statistics] (what a producing kernel does in its epilogue) */
+int bitnet_hip_quantize_act_dev(const float *x_dev, const float *gamma_dev, size_t cols, void *qact_out,
+                                double *stats_out, void *stream);
+/* bitnet_hip_embed_f16_dev for ONE token, also leaving the first block's QAct (gamma_dev = its attention_norm) */
+int bitnet_hip_embed_q_dev(const void *table_f16_dev, const int32_t *tokens_dev, const int32_t *offset_dev,
+                           size_t hidden, size_t vocab, float *x_out_dev, const float *gamma_dev, void *qact_out,
+                           double *stats_out, void *stream);
+int bitnet_hip_gemv_q_supported(bitnet_hip_weights_t w);
+/* bitnet_hip_gemv_fused_dev on a QAct input: y = [residual +] W . act  [LayerNorm: ln_gamma_dev bound + stats_in]
+ * [FUSE_SILU_MUL]; outputs: y_dev f32 (nullable) and / or qact_out [* gamma_out_dev] [+ stats_out]. */
+int bitnet_hip_gemv_q_dev(bitnet_hip_weights_t w, const void *qact_in, const double *stats_in,
+                          const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags,
+                          float *y_dev, void *qact_out, const float *gamma_out_dev, double *stats_out, void *stream);
+/* bitnet_hip_attention_decode[_wide]_dev whose combine step also (or only: out_dev NULL) leaves the QAct of the
+ * attention output for the o-projection */
+int bitnet_hip_attention_decode_q_dev(const float *qkv_dev, const float *rope_sin_dev, const float *rope_cos_dev,
+                                      float *kcache_dev, float *vcache_dev, size_t n_heads, size_t n_kv_heads,
+                                      size_t head_dim, size_t max_pos, const int32_t *pos_dev, float *scratch_dev,
+                                      int wide, float *out_dev, void *qact_out, void *stream);
+/* bitnet_hip_gemv_attn_merge_dev (short contexts) with the QAct outputs of gemv_q_dev */
+int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
+                                     size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
+                                     const float *residual_dev, void *qact_out, const float *gamma_out_dev,
+                                     double *stats_out, void *stream);
 /* The same attention for a whole prompt of seq_len tokens on a FRESH cache (positions
  * 0..seq_len-1): RoPE, cache append, causal GQA softmax attention (T:398-543 with the causal
  * mask T:452-470).  qkv_dev: [seq_len, n_heads*D + 2*n_kv*D]; out_dev: [seq_len, n_heads*D].
