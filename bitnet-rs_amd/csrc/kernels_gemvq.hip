@@ -79,6 +79,19 @@ __device__ __forceinline__ double wave_sum_dq(double v) {
     return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
+// In-kernel time stamps (s_memrealtime, 100 MHz): diagnostic build only (-DBH_STAMPS), 16 x u64 per workgroup.
+#ifdef BH_STAMPS
+#define BH_QSTAMP(i)                                                                                           \
+    do {                                                                                                       \
+        if (p.stamps && lane == 0 && (wave == 0 || wave == NW - 1))                                            \
+            p.stamps[(size_t)blockIdx.x * 16 + (wave ? 8 : 0) + (i)] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+#else
+#define BH_QSTAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
 struct GemvQArgs {
     const uint8_t *tiles;    // [n_tiles][nblk][64 lanes][16 B] code tiles (k_retile)
     const void *stiles;      // [n_tiles][nblk][64 lanes] x {f16 x 2 | f32 x 2}: 32-block scales (k_retile_scales[_h]) or null
@@ -97,23 +110,37 @@ struct GemvQArgs {
     uint8_t *qout;           // optional QAct output (for the next GEMV)
     const float *gamma_out;  // optional: the next GEMV's LayerNorm weight (u = v * gamma)
     double *stats_out;       // optional: (sum, sum of squares) per 16 output rows
+    unsigned long long *stamps;  // diagnostic builds only
 };
 
 // NW waves per workgroup; RING = 256-column blocks per wave, all in flight at once; SC = weight scales per 32-block:
-// 0 none (QK256), 1 f32, 2 f16; NS = LayerNorm statistics pairs per lane (0 = no LayerNorm).
-// Every global load is unconditional and sits ahead of one scheduling fence (kernels_mfma.hip explains why).
-template <int NW, int RING, int SC, int NS>
+// 0 none (QK256), 1 f32, 2 f16; LN = LayerNorm after the product; NCP = 8-KiB passes of the cooperative QAct copy.
+//
+// Where a launch's time goes (in-kernel stamps, tools/stamp_gemvq.py, 2B-4T shapes): a CU's vector-memory path takes
+// 64 B of requests per clock, so WHAT A WORKGROUP ASKS FOR is its start-up time -- with every wave fetching its own K
+// range of the activations and its own copy of the statistics the last wave's weight loads were only requested 1.1 us
+// after the kernel began (99 KB per workgroup, half of it duplicates).  Hence: the workgroup copies the activation
+// vector into LDS ONCE (each thread 16 B), the statistics pairs likewise, and the per-row operands of the epilogue
+// (g_r, residual, the next LayerNorm's gamma) are requested up front too -- behind the barrier they were dependent
+// L2 / HBM round trips (0.7-0.8 us of a 2.5 us kernel).
+// Every global load is unconditional and sits ahead of a scheduling fence (kernels_mfma.hip explains why).
+template <int NW, int RING, int SC, int LN, int NCP>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
-    constexpr int NQ = (RING * kQRec + 1023) / 1024;  // 1-KiB flat copies covering this wave's QAct range
-    constexpr int WQ = NQ * 1024;
+    constexpr int NT = NW * 64;
+    constexpr int ZB = RING * kQRec;  // zero bytes the dead A lanes read (no masking instructions)
+    // every kernel argument in ONE scalar-load round: left alone hipcc fetches some of them where they are first used,
+    // each a dependent round trip on the path to the first vector load
+    asm volatile("" ::"s"(p.tiles), "s"(p.stiles), "s"(p.rows), "s"(p.nblk), "s"(p.lut), "s"(p.ks_log2), "s"(p.qin), "s"(p.stats_in), "s"(p.n_stats),
+                 "s"(p.ln_g), "s"(p.residual), "s"(p.y), "s"(p.silu_mul), "s"(p.qout), "s"(p.gamma_out), "s"(p.stats_out));
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint8_t *wq = lds + wave * 2 * WQ;  // this wave's copy of its QAct records ...
-    uint8_t *zq = wq + WQ;              // ... and as many zero bytes: what the dead A lanes read (no masking instructions)
-    float *part = reinterpret_cast<float *>(lds + NW * 2 * WQ);  // [NW][64] partial sums by K part
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) *reinterpret_cast<v4u *>(zq + 1024 * i + 16 * lane) = v4u{0u, 0u, 0u, 0u};
+    uint8_t *zq = lds;                                // [ZB]
+    uint8_t *cq = lds + ZB;                           // [NCP * 16 * NT] the whole QAct vector (padded)
+    uint8_t *cs = cq + NCP * 16 * NT;                 // [NT * 16] statistics pairs (LN)
+    float *part = reinterpret_cast<float *>(cs + (LN ? NT * 16 : 0));  // [NW][16] partial sums by (tile, K part)
+    BH_QSTAMP(0);
+    if (16 * tid < ZB) *reinterpret_cast<v4u *>(zq + 16 * tid) = v4u{0u, 0u, 0u, 0u};
 
     // ---- wave -> (row tile, K range of at most RING blocks), as k_gemv_mfma ------------------------------------
     const int ksplit = 1 << p.ks_log2;
@@ -125,19 +152,36 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
     if (p.ks_log2 == 3 && wave >= 4) kpart = 11 - wave;  // at most one long range per SIMD (kernels_mfma.hip)
     const int b0 = (kpart * p.nblk) >> p.ks_log2, b1 = ((kpart + 1) * p.nblk) >> p.ks_log2;
 
-    // ---- 1. this wave's QAct range (L2-resident, shared by every workgroup), then the statistics pairs -------
-    const uint32_t q_last = (uint32_t)kQRec * (uint32_t)p.nblk - 16u, qo0 = (uint32_t)kQRec * (uint32_t)b0 + 16u * (uint32_t)lane;
-    v4u qa[NQ];  // native vectors: arrays of HIP's uint4 struct went through scratch memory at the scheduling fence
+    // ---- 1. the activation vector (L2-resident, every workgroup reads it), statistics pairs, epilogue operands ----
+    const uint32_t q_last = (uint32_t)kQRec * (uint32_t)p.nblk - 16u;
+    v4u qa[NCP];  // native vectors: arrays of HIP's uint4 struct went through scratch memory at the scheduling fence
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) qa[i] = *reinterpret_cast<const v4u *>(p.qin + umin32q(qo0 + 1024u * i, q_last));
-    v4u st[NS ? NS : 1];  // (sum, sum of squares) f64 pairs, kept as raw dwords until the epilogue
-    if (NS) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int idx = lane + 64 * i;
-            st[i] = *reinterpret_cast<const v4u *>(p.stats_in + 2 * (size_t)(idx < p.n_stats ? idx : p.n_stats - 1));
-        }
+    for (int i = 0; i < NCP; ++i) qa[i] = *reinterpret_cast<const v4u *>(p.qin + umin32q(16u * (uint32_t)(tid + NT * i), q_last));
+    v4u st = {0u, 0u, 0u, 0u};
+    if (LN) st = *reinterpret_cast<const v4u *>(p.stats_in + 2 * (size_t)(tid < p.n_stats ? tid : p.n_stats - 1));
+    // the storing thread's row(s); other threads request clamped, valid addresses and drop the values
+    const int e_tl = tid >> 4, e_r = tid & 15;
+    int e_row, e_g0 = 0, e_g1 = 0;
+    if (!p.silu_mul) {
+        e_row = 16 * (blockIdx.x * tiles_per_wg + e_tl) + e_r;
+        e_row = e_row < p.rows ? e_row : p.rows - 1;
+        e_g0 = e_row;
+    } else {
+        const int half_rows = p.rows >> 1;
+        const int pg = blockIdx.x * (tiles_per_wg >> 1) + e_tl;
+        e_row = 16 * pg + e_r;
+        e_row = e_row < half_rows ? e_row : half_rows - 1;
+        e_g0 = 32 * (e_row >> 4) + e_r;
+        e_g1 = e_g0 + 16;
     }
+    float e_lg0 = 0.0f, e_lg1 = 0.0f;
+    if (LN) {
+        e_lg0 = p.ln_g[e_g0];
+        e_lg1 = p.ln_g[e_g1];
+    }
+    // nullable operands: a valid dummy address instead of a branch around the load (a load under a branch costs a full wait)
+    const float e_res = (p.residual ? p.residual : reinterpret_cast<const float *>(p.qin))[p.residual ? e_row : 0];
+    const float e_gam = (p.gamma_out ? p.gamma_out : reinterpret_cast<const float *>(p.qin))[p.gamma_out ? e_row : 0];
     // vmcnt retires in order: the activations must be REQUESTED ahead of the weight stream, or their arrival only
     // counts once every weight tile has landed
     __builtin_amdgcn_sched_barrier(0);
@@ -158,19 +202,25 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);  // every load of this wave is requested before anything waits
+    BH_QSTAMP(1);
 
-    // ---- 3. QAct records -> LDS (this wave's own region: LDS executes a wave's accesses in order) --------------
+    // ---- 3. QAct records (and statistics pairs) -> LDS, once per workgroup ------------------------------------
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) *reinterpret_cast<v4u *>(wq + 1024 * i + 16 * lane) = qa[i];
+    for (int i = 0; i < NCP; ++i) *reinterpret_cast<v4u *>(cq + 16 * (tid + NT * i)) = qa[i];
+    if (LN) *reinterpret_cast<v4u *>(cs + 16 * tid) = st;
+    // raw barrier: __syncthreads() would also wait for the weight loads in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // A-operand lane (k-group g, selector row c = 4 kg + 2 d + h): digit plane d of k-group kg, live in the MFMAs
     // of parity h only; every other (lane, MFMA) reads zeros.  D lane (g, c): selector group g, weight row c.
     const int g = lane >> 4, c = lane & 15;
     const bool mine = (c >> 2) == g;
+    const uint8_t *wq = cq + kQRec * b0;  // this wave's K range
     const uint8_t *live = wq + 256 * ((c >> 1) & 1) + 64 * g;
     const uint8_t *ba0 = (mine && (c & 1) == 0) ? live : zq;  // MFMAs 0 and 2 of a block
     const uint8_t *ba1 = (mine && (c & 1) == 1) ? live : zq;  // MFMAs 1 and 3
     const uint8_t *sa = wq + 512 + 16 * g;                    // this lane's four group scales of a record
+    BH_QSTAMP(2);
 
     float facc = 0.0f;
 #pragma unroll
@@ -197,20 +247,31 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
                 facc += t;
         }
     }
-    part[(((wave >> p.ks_log2) << p.ks_log2) + kpart) * 64 + lane] = facc;
+    // the four k-groups of a weight row sit in lanes c, c + 16, c + 32, c + 48: two lane swaps (v_permlane16_swap,
+    // v_permlane32_swap) add them up in every wave at once -- (g0 + g1) + (g2 + g3) -- instead of 4 LDS reads per K part
+    // in the one storing wave
+    {
+        // inline asm with the hazard pad inside (a VALU write needs 2 wait states before v_permlane*_swap reads it):
+        // hipcc's __builtin_amdgcn_permlane16_swap folded the two results into one register here (ROCm 7.2)
+        float a = facc, b = facc;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        facc = a + b;  // rows (g0 + g1, g0 + g1, g2 + g3, g2 + g3)
+        a = facc, b = facc;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        facc = a + b;
+    }
+    if (lane < 16) part[(((wave >> p.ks_log2) << p.ks_log2) + kpart) * 16 + lane] = facc;
+    BH_QSTAMP(3);
 
     // ---- 4. epilogue: the storing waves only ------------------------------------------------------------------
     const bool storing = wave * 64 < tiles_per_wg * 16;
     double ln_mean = 0.0, ln_rdenom = 1.0;
-    if (NS && storing) {
+    if (LN && storing) {
         double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const bool in = lane + 64 * i < p.n_stats;
-            const double a = __builtin_bit_cast(double, ((unsigned long long)st[i][1] << 32) | st[i][0]);
-            const double b = __builtin_bit_cast(double, ((unsigned long long)st[i][3] << 32) | st[i][2]);
-            s1 += in ? a : 0.0;
-            s2 += in ? b : 0.0;
+        for (int i = lane; i < p.n_stats; i += 64) {
+            const double2 pr = *reinterpret_cast<const double2 *>(cs + 16 * i);
+            s1 += pr.x;
+            s2 += pr.y;
         }
         s1 = wave_sum_dq(s1);
         s2 = wave_sum_dq(s2);
@@ -223,41 +284,53 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
         ln_rdenom = r * (2.0 - denom * r);
     }
     __syncthreads();
+    BH_QSTAMP(4);
     if (!storing) return;
-    const int tl = tid >> 4, r = tid & 15;
+    const int tl = e_tl, r = e_r;
     if (!p.silu_mul) {
         if (tl >= tiles_per_wg) return;
         const int t_glob = blockIdx.x * tiles_per_wg + tl;
         if (t_glob >= n_tiles) return;  // whole 16-lane rows leave together
         const int row = 16 * t_glob + r;
+        float pv[NW];
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) pv[kp] = part[((tl << p.ks_log2) + (kp < ksplit ? kp : 0)) * 16 + r];  // all reads in flight at once
         float v = 0.0f;
-        for (int kp = 0; kp < ksplit; ++kp) {
-            const float *pp = part + ((tl << p.ks_log2) + kp) * 64 + r;
-            v += (pp[0] + pp[16]) + (pp[32] + pp[48]);
-        }
-        if (NS) v = (float)(((double)v - ln_mean * (double)p.ln_g[row]) * ln_rdenom);
-        if (p.residual) v += p.residual[row];
+#pragma unroll
+        for (int kp = 0; kp < NW; ++kp) v += kp < ksplit ? pv[kp] : 0.0f;  // fixed order: K parts 0, 1, ...
+        if (LN) v = (float)(((double)v - ln_mean * (double)e_lg0) * ln_rdenom);
+        if (p.residual) v += e_res;
         if (p.y) p.y[row] = v;
-        if (p.qout) qact_emit(p.qout, p.stats_out, t_glob, r, v, p.gamma_out ? v * p.gamma_out[row] : v);
+        if (p.qout) qact_emit(p.qout, p.stats_out, t_glob, r, v, p.gamma_out ? v * e_gam : v);
+        BH_QSTAMP(5);
     } else {
         const int pairs_per_wg = tiles_per_wg >> 1;
         if (tl >= pairs_per_wg) return;
         const int p_glob = blockIdx.x * pairs_per_wg + tl;
         if (2 * p_glob >= n_tiles) return;
         const int row = 16 * p_glob + r;  // row of silu(gate) * up
+        float pg[NW / 2], pu[NW / 2];  // paired matrices split K over at most NW / 2 waves
+#pragma unroll
+        for (int kp = 0; kp < NW / 2; ++kp) {
+            pg[kp] = part[(((2 * tl) << p.ks_log2) + (kp < ksplit ? kp : 0)) * 16 + r];
+            pu[kp] = part[(((2 * tl + 1) << p.ks_log2) + (kp < ksplit ? kp : 0)) * 16 + r];
+        }
         float gv = 0.0f, uv = 0.0f;
-        for (int kp = 0; kp < ksplit; ++kp) {
-            const float *pg = part + (((2 * tl) << p.ks_log2) + kp) * 64 + r, *pu = part + (((2 * tl + 1) << p.ks_log2) + kp) * 64 + r;
-            gv += (pg[0] + pg[16]) + (pg[32] + pg[48]);
-            uv += (pu[0] + pu[16]) + (pu[32] + pu[48]);
+#pragma unroll
+        for (int kp = 0; kp < NW / 2; ++kp) {
+            gv += kp < ksplit ? pg[kp] : 0.0f;
+            uv += kp < ksplit ? pu[kp] : 0.0f;
         }
-        if (NS) {  // stored rows of the paired matrix: (gate tile, up tile)
-            gv = (float)(((double)gv - ln_mean * (double)p.ln_g[32 * p_glob + r]) * ln_rdenom);
-            uv = (float)(((double)uv - ln_mean * (double)p.ln_g[32 * p_glob + 16 + r]) * ln_rdenom);
+        if (LN) {  // stored rows of the paired matrix: (gate tile, up tile)
+            gv = (float)(((double)gv - ln_mean * (double)e_lg0) * ln_rdenom);
+            uv = (float)(((double)uv - ln_mean * (double)e_lg1) * ln_rdenom);
         }
-        const float v = gv / (1.0f + expf(-gv)) * uv;  // FeedForward::forward T:756-781
+        // FeedForward::forward T:756-781: silu(g) * u, silu(v) = v / (1 + e^-v); v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the
+        // ~40-instruction libm forms: this runs on ONE wave per workgroup, behind the barrier
+        const float v = gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)) * uv;
         if (p.y) p.y[row] = v;
-        if (p.qout) qact_emit(p.qout, p.stats_out, p_glob, r, v, p.gamma_out ? v * p.gamma_out[row] : v);
+        if (p.qout) qact_emit(p.qout, p.stats_out, p_glob, r, v, p.gamma_out ? v * e_gam : v);
+        BH_QSTAMP(5);
     }
 }
 
@@ -336,23 +409,26 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
     a.qout = static_cast<uint8_t *>(io.qout);
     a.gamma_out = io.gamma_out;
     a.stats_out = io.stats_out;
+    a.stamps = g_mfma_stamps;
     if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
     const int tiles_per_wg = nw / ksplit;
     const unsigned grid = (unsigned)div_ceil(w.rows / 16, (size_t)tiles_per_wg);
     const int ring = (int)div_ceil((size_t)a.nblk, (size_t)ksplit);
-    const int ns = !ln ? 0 : a.n_stats <= 192 ? 3 : a.n_stats <= 256 ? 4 : -1;
-    if (ring > 5 || ns < 0) return hipErrorInvalidValue;
+    const size_t qbytes = (size_t)kQRec * a.nblk;
+    const int ncp = (int)div_ceil(qbytes, (size_t)16 * nw * 64);
+    if (ring > 5 || ncp > 3 || (ln && a.n_stats > nw * 64)) return hipErrorInvalidValue;
     void (*kfn)(GemvQArgs) = nullptr;
-#define BH_QPICK(RINGv)                                                                                                             \
-    if (!kfn && ring <= RINGv)                                                                                                      \
-        kfn = ns == 0 ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 0> : sc == 1 ? k_gemv_q<8, RINGv, 1, 0> : k_gemv_q<8, RINGv, 0, 0>)         \
-              : ns == 3 ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 3> : sc == 1 ? k_gemv_q<8, RINGv, 1, 3> : k_gemv_q<8, RINGv, 0, 3>)       \
-                        : (sc == 2 ? k_gemv_q<8, RINGv, 2, 4> : sc == 1 ? k_gemv_q<8, RINGv, 1, 4> : k_gemv_q<8, RINGv, 0, 4>);
+#define BH_QPICK2(RINGv, NCPv)                                                                                                        \
+    if (!kfn && ring <= RINGv && ncp == NCPv)                                                                                         \
+        kfn = ln ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 1, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 1, NCPv> : k_gemv_q<8, RINGv, 0, 1, NCPv>)  \
+                 : (sc == 2 ? k_gemv_q<8, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 0, NCPv> : k_gemv_q<8, RINGv, 0, 0, NCPv>);
+#define BH_QPICK(RINGv) BH_QPICK2(RINGv, 1) BH_QPICK2(RINGv, 2) BH_QPICK2(RINGv, 3)
     BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
 #undef BH_QPICK
+#undef BH_QPICK2
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;
-    const size_t lds = (size_t)nw * 2 * (((size_t)ring_t * kQRec + 1023) / 1024 * 1024) + (size_t)nw * 64 * sizeof(float);
+    const size_t lds = (size_t)ring_t * kQRec + (size_t)ncp * 16 * nw * 64 + (ln ? (size_t)nw * 64 * 16 : 0) + (size_t)nw * 16 * sizeof(float);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, stream, a);
     return hipGetLastError();
 }

@@ -45,7 +45,7 @@ def test_quantiser_bit_exact(hip, torch_, n):
     cases = [rng.normal(0, 1, n), rng.normal(3, 50, n), rng.uniform(-1e-3, 1e-3, n), np.zeros(n), rng.normal(0, 1, n) * (rng.random(n) < 0.1)]
     big = rng.normal(0, 1, n)
     big[::16] = 2.0 ** rng.integers(-20, 20, n // 16)  # group maxima exactly on powers of two
-    big[5::32] = -1e20                                  # and huge ones
+    big[5::32] = -1e15                                  # and huge ones (squares still inside f32: the statistics are f32 sums)
     cases.append(big)
     tiny = rng.normal(0, 1e-30, n)
     cases.append(tiny)
@@ -59,7 +59,8 @@ def test_quantiser_bit_exact(hip, torch_, n):
         assert np.array_equal(got, want), (n, ci)
         s = st.cpu().numpy().reshape(-1, 2)
         x64 = x.astype(np.float64).reshape(-1, 16)
-        assert np.allclose(s[:, 0], x64.sum(1), rtol=1e-14, atol=1e-300) and np.allclose(s[:, 1], (x64 * x64).sum(1), rtol=1e-14, atol=1e-300)
+        # f32 sums over the 16 values (stored as f64): ~1e-7 of the sum of magnitudes
+        assert np.all(np.abs(s[:, 0] - x64.sum(1)) <= 1e-6 * np.abs(x64).sum(1) + 1e-300) and np.allclose(s[:, 1], (x64 * x64).sum(1), rtol=4e-6, atol=1e-300)
         # and the format holds every element to 2^-15 of its group's maximum
         u = x if gamma is None else x * gamma
         back = dequantize_qact(want, n)
@@ -120,7 +121,8 @@ def test_gemv_q_against_dequantised_product(hip, torch_, rows, cols, fmt):
     assert np.array_equal(v, y.cpu().numpy() + res)
     assert np.array_equal(qo.cpu().numpy()[: (rows + 255) // 256 * QREC], quantize_qact(v, gam)[: (rows + 255) // 256 * QREC])
     s = so.cpu().numpy().reshape(-1, 2)
-    assert np.allclose(s[:, 0], v.astype(np.float64).reshape(-1, 16).sum(1), rtol=1e-14)
+    v64 = v.astype(np.float64).reshape(-1, 16)
+    assert np.all(np.abs(s[:, 0] - v64.sum(1)) <= 1e-6 * np.abs(v64).sum(1)) and np.allclose(s[:, 1], (v64 * v64).sum(1), rtol=4e-6)
     hip.weights_free(h)
 
 
