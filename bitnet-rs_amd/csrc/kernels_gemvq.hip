@@ -23,8 +23,7 @@
 // held to 2^-15 of its 16-group's maximum (qact.hpp); f32 accumulation in a fixed order (bit-reproducible).
 // Reference semantics: Q/i2s_qk256.rs:196-274 (QK256), K/cpu/quantized_matmul.rs:57-96 (ternary x block scale),
 // T:67-100 (LayerNorm), T:756-781 (silu(gate) * up), T:1073 / T:1125 (residual).
-#include <mutex>
-#include <unordered_set>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "qact.hpp"
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
     int tile = blockIdx.x * tiles_per_wg + (wave >> p.ks_log2);
     tile = tile < n_tiles ? tile : n_tiles - 1;  // surplus waves redo the last tile; never stored
     int kpart = wave & (ksplit - 1);
-    if (p.ks_log2 == 3 && wave >= 4) kpart = 11 - wave;  // at most one long range per SIMD (kernels_mfma.hip)
+    if (NW == 8 && p.ks_log2 == 3 && wave >= 4) kpart = 11 - wave;  // at most one long range per SIMD (kernels_mfma.hip)
     const int b0 = (kpart * p.nblk) >> p.ks_log2, b1 = ((kpart + 1) * p.nblk) >> p.ks_log2;
 
     // ---- 1. the activation vector (L2-resident, every workgroup reads it), statistics pairs, epilogue operands ----
@@ -392,9 +391,15 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
     a.cols = (int)w.cols;
     a.nblk = (int)(w.cols / 256);
     a.lut = w.lut;
-    const int nw = 8;
-    const int ksplit = mfma_pick_ksplit(w.rows, w.cols, io.silu_mul, nw);
-    a.ks_log2 = ksplit == 8 ? 3 : ksplit == 4 ? 2 : ksplit == 2 ? 1 : 0;
+    // tuning knob, read once: 16-wave workgroups (4 waves per SIMD, half the K range each; same grid as the 8-wave form) --
+    // bit 0: paired matrices (gate|up), bit 1: K of >= 16 blocks (down)
+    static const int nw16_mask = getenv("BITNET_HIP_Q_NW16") ? atoi(getenv("BITNET_HIP_Q_NW16")) : 0;
+    const int ks8 = mfma_pick_ksplit(w.rows, w.cols, io.silu_mul, 8);
+    const bool nw16 = ((nw16_mask & 1) && io.silu_mul && ks8 <= 4 && (size_t)(2 * ks8) <= w.cols / 256) ||
+                      ((nw16_mask & 2) && !io.silu_mul && ks8 == 8 && w.cols / 256 >= 16);
+    const int nw = nw16 ? 16 : 8;
+    const int ksplit = nw16 ? 2 * ks8 : ks8;
+    a.ks_log2 = ksplit == 16 ? 4 : ksplit == 8 ? 3 : ksplit == 4 ? 2 : ksplit == 2 ? 1 : 0;
     a.qin = static_cast<const uint8_t *>(io.qin);
     const bool ln = io.ln_gamma != nullptr;
     if (ln && !(w.ln_g && w.ln_gamma_bound == io.ln_gamma && io.stats_in)) return hipErrorInvalidValue;  // LayerNorm only in the after-product form
@@ -423,9 +428,17 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
         kfn = ln ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 1, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 1, NCPv> : k_gemv_q<8, RINGv, 0, 1, NCPv>)  \
                  : (sc == 2 ? k_gemv_q<8, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 0, NCPv> : k_gemv_q<8, RINGv, 0, 0, NCPv>);
 #define BH_QPICK(RINGv) BH_QPICK2(RINGv, 1) BH_QPICK2(RINGv, 2) BH_QPICK2(RINGv, 3)
-    BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
+    if (nw == 8) {
+        BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
+    }
 #undef BH_QPICK
 #undef BH_QPICK2
+#define BH_QPICK16(RINGv, NCPv)                                                                                                          \
+    if (!kfn && nw == 16 && ring <= RINGv && ncp == NCPv)                                                                                \
+        kfn = ln ? (sc == 2 ? k_gemv_q<16, RINGv, 2, 1, NCPv> : sc == 1 ? k_gemv_q<16, RINGv, 1, 1, NCPv> : k_gemv_q<16, RINGv, 0, 1, NCPv>)  \
+                 : (sc == 2 ? k_gemv_q<16, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<16, RINGv, 1, 0, NCPv> : k_gemv_q<16, RINGv, 0, 0, NCPv>);
+    BH_QPICK16(2, 1) BH_QPICK16(2, 2) BH_QPICK16(3, 1) BH_QPICK16(3, 2) BH_QPICK16(4, 1) BH_QPICK16(4, 2)
+#undef BH_QPICK16
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;
     const size_t lds = (size_t)ring_t * kQRec + (size_t)ncp * 16 * nw * 64 + (ln ? (size_t)nw * 64 * 16 : 0) + (size_t)nw * 16 * sizeof(float);

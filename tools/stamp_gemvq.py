@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layers", type=int, default=30)
     ap.add_argument("--replays", type=int, default=3)
     ap.add_argument("--fmt", default="i2s32", choices=["qk256", "i2s32"])
+    ap.add_argument("--same", action="store_true", help="every launch of the graph reads the SAME matrix (L2 / MALL resident): the upper bound a weight prefetch could reach")
     args = ap.parse_args()
     hip = pkg.HipLib(pkg.LIB_PATH.replace(".so", "_diag.so"))
     hip.init(0)
@@ -43,13 +44,15 @@ def main():
     paired = args.shape == "gateup"
     ln = args.shape in ("gateup", "qkv")
     handles = []
-    for _ in range(args.layers):
+    for _ in range(1 if args.same else args.layers):
         if paired:
             a, b = mk(), mk()
             handles.append(hip.weights_concat([a, b], interleave16=True))
             hip.weights_free(a), hip.weights_free(b)
         else:
             handles.append(mk())
+    if args.same:
+        handles = handles * args.layers
     gamma = torch.full((cols,), 0.0125, device="cuda")
     if ln:
         for h in handles:
