@@ -418,3 +418,19 @@ def rope_tables(dim: int, max_seq_len: int, base: float):
     L.bo_rope_build_tables.argtypes = [C.c_int, C.c_int, C.c_float, _f32p, _f32p]
     L.bo_rope_build_tables(dim, max_seq_len, base, sin.ctypes.data_as(_f32p), cos.ctypes.data_as(_f32p))
     return sin, cos
+
+
+def rope_apply(x, pos: int, base: float = 10000.0) -> np.ndarray:
+    """RotaryEmbedding::apply on head vectors [..., dim] at one position (T:134-163): split-half pairing (i, i + dim/2),
+    tables from bo_rope_build_tables (crates/bitnet-rope/src/lib.rs:59-93)."""
+    xa = np.ascontiguousarray(x, np.float32).copy()
+    dim = xa.shape[-1]
+    sin, cos = rope_tables(dim, pos + 1, base)
+    L = lib()
+    L.bo_rope_apply.argtypes = [_f32p, C.c_int, _f32p, _f32p]
+    flat = xa.reshape(-1, dim)
+    for r in range(flat.shape[0]):
+        row = np.ascontiguousarray(flat[r])
+        L.bo_rope_apply(row.ctypes.data_as(_f32p), dim, sin[pos].ctypes.data_as(_f32p), cos[pos].ctypes.data_as(_f32p))
+        flat[r] = row
+    return flat.reshape(xa.shape)
