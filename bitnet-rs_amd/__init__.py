@@ -501,6 +501,7 @@ class GgufFile:
         L.bitnet_host_gguf_config.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.bitnet_host_gguf_detect_i2s_flavor.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         L.bitnet_host_gguf_loader_is_qk256.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64]
+        L.bitnet_host_gguf_check_projection.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
         self.h = None
         if path is not None:
             self.h = L.bitnet_host_gguf_open(path.encode())
@@ -551,6 +552,12 @@ class GgufFile:
         if rc < 0:
             raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error())
         return FLAVORS[rc]
+
+    def check_projection(self, idx: int, rows: int, cols: int) -> None:
+        """The loader's per-projection step without a device (flavour decision, size / bounds checks, codes + scales
+        split); raises with the loader's message when the tensor would be refused."""
+        if self.c.bitnet_host_gguf_check_projection(self.h, idx, rows, cols) != 0:
+            raise BitNetHipError(ERR_INVALID_ARGUMENT, self.error())
 
     def loader_is_qk256(self, shape, available: int) -> bool:
         sh = (C.c_uint64 * len(shape))(*shape)

@@ -511,6 +511,14 @@ bool make_spec(const GgufFile &g, const GgufTensor &t, size_t rows, size_t cols,
             err = "I2SQk256NoScale: data size mismatch for '" + t.name + "': got " + std::to_string(avail) + ", expected " + std::to_string(need);
             return false;
         }
+        {
+            const size_t abs = g.data_start() + (size_t)t.offset;
+            if (abs > g.file_len() || avail > g.file_len() - abs) {
+                err = "I2_S '" + t.name + "': insufficient file data (need " + std::to_string(avail) + " at " + std::to_string(abs) + ", file " +
+                      std::to_string(g.file_len()) + ")";
+                return false;
+            }
+        }
         sp.qk256 = true;
         sp.bytes = g.tensor_data(t);
         sp.len = avail;
@@ -540,6 +548,16 @@ bool make_spec(const GgufFile &g, const GgufTensor &t, size_t rows, size_t cols,
         err = "I2_S '" + t.name + "': available bytes " + std::to_string(avail) + " don't match BitNet split (" +
               std::to_string(split_need) + " +- 128) or inline (" + std::to_string(inline_need) + " +- 128)";
         return false;
+    }
+    {
+        // `need` may exceed the tensor's own byte count by the 128-byte slack: the reference then reads on into whatever
+        // follows in the file and refuses only past its end (gguf_simple.rs:1196-1207) -- the same bound, the same words
+        const size_t abs = g.data_start() + (size_t)t.offset;
+        if (abs > g.file_len() || need > g.file_len() - abs) {
+            err = "I2_S '" + t.name + "': insufficient file data (need " + std::to_string(need) + " at " + std::to_string(abs) + ", file " +
+                  std::to_string(g.file_len()) + ")";
+            return false;
+        }
     }
     const uint8_t *raw = g.tensor_data(t);
     const GgufTensor *sib = g.find_sibling_scale(t.name);
@@ -710,6 +728,31 @@ int bitnet_host_gguf_detect_i2s_flavor(uint64_t available, uint64_t nelems, int 
 }
 int bitnet_host_gguf_loader_is_qk256(const uint64_t *shape, uint32_t n_dims, uint64_t available) {
     return loader_is_qk256(std::vector<uint64_t>(shape, shape + n_dims), (size_t)available) ? 1 : 0;
+}
+int bitnet_host_gguf_check_projection(void *gp, int64_t idx, uint64_t rows, uint64_t cols) {
+    if (!gp) return -1;
+    const GgufFile &g = *static_cast<GgufFile *>(gp);
+    if (idx < 0 || (size_t)idx >= g.tensors().size()) {
+        g_gguf_error = "tensor index out of range";
+        return -1;
+    }
+    if (rows == 0 || cols == 0 || rows > (1ull << 31) || cols > (1ull << 31)) {
+        g_gguf_error = "bad projection shape";
+        return -1;
+    }
+    ProjSpec sp;
+    ProjStorage st;
+    std::string err;
+    if (!make_spec(g, g.tensors()[(size_t)idx], (size_t)rows, (size_t)cols, sp, st, err)) {
+        g_gguf_error = err;
+        return -1;
+    }
+    // every byte an upload would read
+    volatile uint64_t sink = 0;
+    for (size_t i = 0; i < sp.len; ++i) sink += sp.bytes[i];
+    for (size_t i = 0; i < sp.n_scales; ++i) sink += sp.scales[i] != 0.0f;
+    (void)sink;
+    return 0;
 }
 int bitnet_host_load_gguf(void *decoder, void *g) {
     if (!decoder || !g) return BITNET_HIP_ERR_INVALID_ARGUMENT;

@@ -75,6 +75,7 @@ class GgufFile {
     uint32_t version() const { return version_; }
     uint32_t alignment() const { return alignment_; }
     size_t data_start() const { return data_start_; }
+    size_t file_len() const { return len_; }
     const std::vector<GgufTensor> &tensors() const { return tensors_; }
     const GgufTensor *find(const std::string &name) const;
     const uint8_t *tensor_data(const GgufTensor &t) const { return data_ + data_start_ + t.offset; }
@@ -115,6 +116,10 @@ uint64_t bitnet_host_gguf_data_start(void *g);
 int bitnet_host_gguf_config(void *g, uint64_t *cfg, float *f);
 int bitnet_host_gguf_detect_i2s_flavor(uint64_t available, uint64_t nelems, int has_scale_sibling, int strict);
 int bitnet_host_gguf_loader_is_qk256(const uint64_t *shape, uint32_t n_dims, uint64_t available);
+// The loader's per-projection step WITHOUT a device: tensor `idx` as an I2_S projection [rows, cols] through the flavour
+// decision, size / bounds checks and the split into codes + scales (what load_gguf hands to the uploads), touching every
+// byte it would upload.  0, or -1 + bitnet_host_gguf_error().  Used by the CPU tests and the ASan fuzzer.
+int bitnet_host_gguf_check_projection(void *g, int64_t idx, uint64_t rows, uint64_t cols);
 // Fills an existing decoder (bitnet_host_create with the file's config) from the file.
 int bitnet_host_load_gguf(void *decoder, void *g);
 }

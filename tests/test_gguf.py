@@ -230,3 +230,38 @@ def test_oracle_32_element_flavours_to_f32():
                                   ("pad", (1,), W.F32, bytes(4))]))
     with pytest.raises(G.GgufError, match="expected 180 bytes for inline f16, got 144"):
         G.i2s32_to_f32(g, g.tensors[0])
+
+
+def test_truncated_last_tensor_is_refused_not_read_past_the_file(pkg):
+    """The 32-element flavours accept a byte count within +-128 B of the expected one, but the loader then reads the EXPECTED
+    count: for the file's last tensor that lies past the end of the file.  The reference refuses ("insufficient file data",
+    gguf_simple.rs:1196-1207); a tensor in the middle of the file reads on into its successor, as the reference does."""
+    rng = np.random.default_rng(3)
+    rows, cols = 64, 256  # 512 blocks: split (4096 B) and inline (5120 B) sizes are further apart than the slack
+    nb = rows * cols // 32
+    payload = W.inline_f16_blocks(rng.integers(0, 256, (nb, 8), dtype=np.uint8), rng.uniform(0.5, 1.0, nb).astype(np.float16))
+    assert len(payload) == nb * 10
+    tail = ("pad.weight", (16,), W.F32, bytes(64))
+    for short in (1, 100, 128):
+        # last tensor, `short` bytes missing: inside the +-128 slack, outside the file
+        f = pkg.GgufFile(data=W.write_gguf([], [tail, ("blk.0.attn_q.weight", (rows, cols), W.I2_S, payload[:-short])]))
+        with pytest.raises(pkg.BitNetHipError, match="insufficient file data"):
+            f.check_projection(1, rows, cols)
+        f.close()
+    # the same truncation in the MIDDLE of the file (the aligned successor's bytes are there): accepted
+    f = pkg.GgufFile(data=W.write_gguf([], [("blk.0.attn_q.weight", (rows, cols), W.I2_S, payload[:-20]), ("pad.weight", (64,), W.F32, bytes(256))]))
+    f.check_projection(0, rows, cols)
+    f.close()
+    # complete file: accepted; beyond the slack: the size mismatch message
+    f = pkg.GgufFile(data=W.write_gguf([], [tail, ("blk.0.attn_q.weight", (rows, cols), W.I2_S, payload)]))
+    f.check_projection(1, rows, cols)
+    f.close()
+    f = pkg.GgufFile(data=W.write_gguf([], [tail, ("blk.0.attn_q.weight", (rows, cols), W.I2_S, payload[:-129])]))
+    with pytest.raises(pkg.BitNetHipError, match="don't match BitNet split"):
+        f.check_projection(1, rows, cols)
+    f.close()
+    # QK256 last tensor cut short by less than the slack: I2SQk256NoScale::new would accept the size, gemv_qk256 not the data
+    qrows, qcols = 4, 256
+    f = pkg.GgufFile(data=W.write_gguf([], [tail, ("blk.0.attn_k.weight", (qrows, qcols), W.I2_S, bytes(qrows * 64))]))
+    f.check_projection(1, qrows, qcols)
+    f.close()

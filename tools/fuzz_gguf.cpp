@@ -74,6 +74,13 @@ static void exercise(const std::vector<uint8_t> &buf, uint64_t *ok, uint64_t *ba
         // every byte the table says belongs to the tensor must be inside the buffer
         const uint8_t *d = g->tensor_data(t);
         if (t.size) sink += d[0] + d[t.size - 1];
+        // the loader's projection step (flavour decision, +-128-byte slack, split into codes + scales) reads what an upload
+        // would: as labelled and with the transposed label
+        if (t.shape.size() == 2 && t.shape[0] && t.shape[1] && t.shape[0] < (1u << 20) && t.shape[1] < (1u << 20)) {
+            const int64_t idx = &t - g->tensors().data();
+            (void)bitnet_host_gguf_check_projection(g, idx, t.shape[0], t.shape[1]);
+            (void)bitnet_host_gguf_check_projection(g, idx, t.shape[1], t.shape[0]);
+        }
     }
     delete g;
     free(p);
