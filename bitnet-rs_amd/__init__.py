@@ -124,6 +124,9 @@ class HipLib:
         L.bitnet_hip_matmul_kernel_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, C.c_int, _vp]
         L.bitnet_hip_add_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
         L.bitnet_hip_silu_mul_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _vp]
+        L.bitnet_hip_weights_device_bytes.argtypes = [C.c_uint64]
+        L.bitnet_hip_weights_device_bytes.restype = _sz
+        L.bitnet_hip_weights_trim.argtypes = [C.c_uint64]
         L.bitnet_hip_qact_bytes.argtypes = [_sz]
         L.bitnet_hip_qact_bytes.restype = _sz
         L.bitnet_hip_qact_stats_bytes.argtypes = [_sz]
@@ -354,6 +357,12 @@ class HipLib:
 
     def silu_mul_dev(self, gate, up, out, n: int, tile: int = 0, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_silu_mul_dev(_ptr(gate), _ptr(up), _ptr(out), n, tile, _vp(stream)))
+
+    def weights_device_bytes(self, h: int) -> int:
+        return int(self.c.bitnet_hip_weights_device_bytes(h))
+
+    def weights_trim(self, h: int) -> None:
+        self._check(self.c.bitnet_hip_weights_trim(h))
 
     # ---- QAct: activations quantised by their producer (csrc/qact.hpp) ----
     def qact_bytes(self, cols: int) -> int:

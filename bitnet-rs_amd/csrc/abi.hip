@@ -106,9 +106,11 @@ int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvF
         e = build_tiles(w, stream);  // no-op after the first call (done at upload normally)
         if (e == hipSuccess) e = launch_gemv_mfma(w, x_dev, y_dev, m, fu, stream);
     } else if (kernel == BITNET_HIP_KERNEL_VALU) {
-        e = launch_gemv_valu(w, x_dev, y_dev, m, stream);
+        e = ensure_reference(w, stream);  // the reference-layout copies are dropped at upload and rebuilt for these kernels
+        if (e == hipSuccess) e = launch_gemv_valu(w, x_dev, y_dev, m, stream);
     } else {
-        e = launch_gemv_exact(w, x_dev, y_dev, m, stream);
+        e = ensure_reference(w, stream);
+        if (e == hipSuccess) e = launch_gemv_exact(w, x_dev, y_dev, m, stream);
     }
     if (e != hipSuccess)
         return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
@@ -258,6 +260,7 @@ int bitnet_hip_weights_upload_qk256(const uint8_t *qs_data, size_t qs_len, size_
         free_weights(w);
         return set_error(BITNET_HIP_ERR_GPU, "re-tiling QK256 codes for the MFMA kernel failed");
     }
+    if (mfma_supported(*w)) trim_reference(*w);  // one copy of the weights on the device; ensure_reference() rebuilds on demand
     return register_weights(w, out);
     BH_GUARD_END
 }
@@ -290,6 +293,7 @@ static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float
     w->block_size = block_size;
     w->nblk = nblk;
     w->lut = lut;
+    w->scaled = true;
     if (block_size == 32) {  // f16-exact scales (BitNet32-F16): keep them as f16 in the streaming layout
         bool exact = true;
         for (size_t i = 0; i < n * nblk && exact; ++i) exact = (float)(_Float16)scales[i] == scales[i];
@@ -311,6 +315,7 @@ static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float
         free_weights(w);
         return set_error(BITNET_HIP_ERR_GPU, "re-tiling I2_S codes for the MFMA kernel failed");
     }
+    if (mfma_supported(*w)) trim_reference(*w);
     return register_weights(w, out);
     BH_GUARD_END
 }
@@ -407,6 +412,8 @@ static int matmul_dev_kernel(bitnet_hip_weights_t h, const float *x_dev, float *
         // released IN STREAM ORDER (no host synchronisation, nothing that outlives the call on the host side);
         // callers that replay the call from a hipGraph pass their own workspace to bitnet_hip_matmul_fused_dev.
         const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
+        if (w->scaled && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
+            return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
         void *ws = nullptr;
         if (hipMallocAsync(&ws, wsb, (hipStream_t)stream) != hipSuccess)
             return set_error(BITNET_HIP_ERR_GPU, "hipMallocAsync failed for the matmul workspace (%zu bytes)", wsb);
@@ -454,6 +461,8 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     const size_t need = gemm_workspace_bytes(m, w->cols, digits);
     if (!workspace_dev || workspace_bytes < need)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_dev ? workspace_bytes : (size_t)0);
+    if (w->scaled && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)  // the tiled matmul reads row-major block scales
+        return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
@@ -509,7 +518,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
         const WeightsRef w = lookup(parts[i]);
         if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)parts[i]);
         if (i > 0 && (w->cols != ws[0]->cols || w->row_stride_bytes != ws[0]->row_stride_bytes || w->lut != ws[0]->lut ||
-                      w->block_size != ws[0]->block_size || (w->scales == nullptr) != (ws[0]->scales == nullptr)))
+                      w->block_size != ws[0]->block_size || w->scaled != ws[0]->scaled))
             return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_concat: part %zu differs in cols / code map / scales", i);
         ws.push_back(w);
         rows += w->rows;
@@ -518,6 +527,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_concat: interleave16 needs two parts of equal rows %% 16 == 0");
     Weights *f = new Weights();
     *f = *ws[0];
+    f->mu = std::make_shared<std::mutex>();
     f->codes = nullptr;
     f->scales = nullptr;
     f->tiles = nullptr;
@@ -533,9 +543,61 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
         f->algorithmic_bytes += w->algorithmic_bytes;
         if (w->scales_f16 && !f->scales_f16) f->algorithmic_bytes += 2 * w->rows * w->nblk;  // stored as f32 in the fused matrix
     }
+    // Tile path: every part already lives as 16-row tiles (rows % 16 == 0, except that the last part of a plain
+    // concatenation may be ragged) with one kind of scale tiles -> the fused matrix is the tile arrays laid end to end
+    // (or alternating), no reference-layout copy is ever made.
+    const size_t nblk256 = div_ceil(f->cols, 256);
+    bool tile_path = true;
+    for (size_t i = 0; i < ws.size(); ++i) {
+        const Weights &w = *ws[i];
+        if (!w.tiles || (w.rows % 16 != 0 && (interleave16 || i + 1 != ws.size()))) tile_path = false;
+        if (w.scaled && w.block_size == 32 && !(f->scales_f16 ? w.scale_tiles_h != nullptr : w.scale_tiles != nullptr)) tile_path = false;
+        if (w.scaled && w.block_size != 32) tile_path = false;
+    }
+    bool ok = true;
+    if (tile_path) {
+        const size_t trb = nblk256 * 1024, n_tiles = div_ceil(rows, 16);
+        const bool st = f->scaled, sth = st && f->scales_f16;
+        const size_t srb = nblk256 * 128 * (sth ? sizeof(uint16_t) : sizeof(float));
+        ok = hipMalloc((void **)&f->tiles, n_tiles * trb) == hipSuccess;
+        uint8_t *sdst = nullptr;
+        if (ok && st) {
+            ok = hipMalloc((void **)&sdst, n_tiles * srb) == hipSuccess;
+            if (sth)
+                f->scale_tiles_h = reinterpret_cast<uint16_t *>(sdst);
+            else
+                f->scale_tiles = reinterpret_cast<float *>(sdst);
+        }
+        auto ssrc = [&](const Weights &w) { return sth ? (const uint8_t *)w.scale_tiles_h : (const uint8_t *)w.scale_tiles; };
+        if (ok && interleave16) {
+            const size_t nt = ws[0]->rows / 16;
+            for (int i = 0; i < 2 && ok; ++i) {
+                ok = hipMemcpy2D(f->tiles + i * trb, 2 * trb, ws[i]->tiles, trb, trb, nt, hipMemcpyDeviceToDevice) == hipSuccess;
+                if (ok && st) ok = hipMemcpy2D(sdst + i * srb, 2 * srb, ssrc(*ws[i]), srb, srb, nt, hipMemcpyDeviceToDevice) == hipSuccess;
+            }
+        } else if (ok) {
+            size_t t0 = 0;
+            for (const WeightsRef &w : ws) {
+                const size_t nt = div_ceil(w->rows, 16);
+                ok = ok && hipMemcpy(f->tiles + t0 * trb, w->tiles, nt * trb, hipMemcpyDeviceToDevice) == hipSuccess;
+                if (ok && st) ok = hipMemcpy(sdst + t0 * srb, ssrc(*w), nt * srb, hipMemcpyDeviceToDevice) == hipSuccess;
+                t0 += nt;
+            }
+        }
+        f->n_row_tiles = n_tiles;
+        f->n_kblocks = nblk256;
+        if (!ok) {
+            free_weights(f);
+            return set_error(BITNET_HIP_ERR_GPU, "weights_concat: device allocation or copy failed");
+        }
+        return register_weights(f, out);
+    }
+    // Reference path (odd shapes): the parts' reference layouts are rebuilt if they were dropped
+    for (const WeightsRef &w : ws)
+        if (ensure_reference(*w, nullptr) != hipSuccess) ok = false;
     const size_t stride = f->row_stride_bytes, sstride = f->nblk * sizeof(float);
-    bool ok = hipMalloc((void **)&f->codes, rows * stride + 16) == hipSuccess;
-    if (ok && ws[0]->scales) ok = hipMalloc((void **)&f->scales, rows * sstride) == hipSuccess;
+    ok = ok && hipMalloc((void **)&f->codes, rows * stride + 16) == hipSuccess;
+    if (ok && f->scaled) ok = hipMalloc((void **)&f->scales, rows * sstride) == hipSuccess;
     if (ok && interleave16) {
         const size_t nt = ws[0]->rows / 16;
         for (int i = 0; i < 2 && ok; ++i) {
@@ -554,13 +616,30 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
             r0 += w->rows;
         }
     }
+    for (const WeightsRef &w : ws)
+        if (mfma_supported(*w)) trim_reference(*w);
     if (ok && mfma_supported(*f)) ok = build_tiles(*f, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         free_weights(f);
         return set_error(BITNET_HIP_ERR_GPU, "weights_concat: device allocation or copy failed");
     }
+    if (mfma_supported(*f)) trim_reference(*f);
     return register_weights(f, out);
     BH_GUARD_END
+}
+
+size_t bitnet_hip_weights_device_bytes(bitnet_hip_weights_t h) {
+    const WeightsRef w = lookup(h);
+    if (!w) return 0;
+    std::lock_guard<std::mutex> lk(*w->mu);
+    return weights_device_bytes(*w);
+}
+
+int bitnet_hip_weights_trim(bitnet_hip_weights_t h) {
+    const WeightsRef w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    trim_reference(*w);
+    return BITNET_HIP_OK;
 }
 
 /* ------------------------------------------------ decode-step operators */

@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
+#include <mutex>
 #include <string>
 
 #include "bitnet_hip.h"
@@ -56,8 +58,12 @@ struct Weights {
     size_t block_size = 0;        // scale block along k (0 = no scales)
     size_t nblk = 0;              // scale blocks per row
     uint32_t lut = 0;             // pack_lut(...)
-    uint8_t *codes = nullptr;     // [rows, row_stride_bytes], reference layout
-    float *scales = nullptr;      // [rows, nblk] f32 or null
+    bool scaled = false;          // the matrix has block scales (whichever copies of them are materialised)
+    // Reference layout.  Dropped once the streaming layout below exists (the fast kernels never read it: keeping both doubled
+    // the device memory of a model) and rebuilt on demand by ensure_reference() for the reference-order kernels, under `mu`.
+    uint8_t *codes = nullptr;     // [rows, row_stride_bytes] or null
+    float *scales = nullptr;      // [rows, nblk] f32 or null (always kept for 256-element blocks: 4 B per 256 weights)
+    std::shared_ptr<std::mutex> mu = std::make_shared<std::mutex>();
     size_t algorithmic_bytes = 0; // code bytes + scale bytes
     int device = 0;
     // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
@@ -126,6 +132,11 @@ hipError_t launch_quant_act(const float *x, const float *gamma, size_t n, void *
 hipError_t launch_embed_q(const void *table, const int *tokens, const int *offset_ptr, int hidden, int vocab, float *x_out,
                           const float *gamma, void *qout, double *stats, hipStream_t stream);
 hipError_t build_tiles(Weights &w, hipStream_t stream);
+// codes / scales in the reference layout, rebuilt from the tiles if they were dropped (exact inverse permutation);
+// synchronises `stream` when it had to rebuild.  trim_reference drops them again when the tiles can stand in.
+hipError_t ensure_reference(Weights &w, hipStream_t stream);
+void trim_reference(Weights &w);
+size_t weights_device_bytes(const Weights &w);
 // many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
 bool gemm_supported(const Weights &w);
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);

@@ -420,7 +420,7 @@ static int gemm_ttw(int ndig, int ws) { return ws == 2 ? (ndig <= 3 ? 2 : 1) : (
 bool gemm_supported(const Weights &w) {
     if (!w.tiles || w.cols % 4 != 0 || w.cols > 8192) return false;
     if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;
-    if (w.scales && w.block_size != 256 && !(w.block_size == 32 && w.cols % 256 == 0)) return false;
+    if (w.scaled && w.block_size != 256 && !(w.block_size == 32 && w.cols % 256 == 0)) return false;
     return true;
 }
 
@@ -456,7 +456,8 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
                             void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
     if (workspace_bytes < gemm_workspace_bytes(m, w.cols, ndig) || !workspace) return hipErrorInvalidValue;
-    const int ws_mode = !w.scales ? 0 : w.block_size == 32 ? 2 : 1;
+    const int ws_mode = !w.scaled ? 0 : w.block_size == 32 ? 2 : 1;
+    if (w.scaled && !w.scales) return hipErrorInvalidValue;  // the caller materialises the row-major scales (ensure_reference)
     const size_t wg_tokens = (size_t)32 * gemm_ttw(ndig, ws_mode), m_pad = div_ceil(m, wg_tokens) * wg_tokens;
     QuantArgs q;
     q.x = x;

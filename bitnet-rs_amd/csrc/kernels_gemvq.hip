@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_embed_q(const _Float16 *__restrict__ ta
 bool gemvq_supported(const Weights &w) {
     if (!mfma_supported(w)) return false;
     if (w.cols % 256 != 0 || w.rows % 16 != 0) return false;   // whole records, whole producer tiles
-    if (w.scales && w.block_size != 32) return false;          // 256-block scales stay on k_gemv_mfma
+    if (w.scaled && w.block_size != 32) return false;          // 256-block scales stay on k_gemv_mfma
     return true;
 }
 
@@ -380,7 +380,7 @@ hipError_t launch_embed_q(const void *table, const int *tokens, const int *offse
 
 hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream) {
     if (!w.tiles || !gemvq_supported(w)) return hipErrorInvalidValue;
-    const bool sc_any = w.scales != nullptr;
+    const bool sc_any = w.scaled;
     const int sc = !sc_any ? 0 : w.scales_f16 ? 2 : 1;
     if (sc == 2 && !w.scale_tiles_h) return hipErrorInvalidValue;
     if (sc == 1 && !w.scale_tiles) return hipErrorInvalidValue;

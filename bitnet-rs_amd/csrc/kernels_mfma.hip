@@ -636,8 +636,8 @@ bool mfma_supported(const Weights &w) {
     if (w.cols > (size_t)kNVMAX * 2048) return false;                    // prologue register budget
     if (w.cols % 4 != 0) return false;                                   // float4 activation loads
     if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return false;  // QK256-shaped rows
-    if (w.scales && w.block_size != 256 && w.block_size != 32) return false;  // f32 scales per 256- or 32-block
-    if (w.scales && w.block_size == 32 && w.cols % 256 != 0) return false;
+    if (w.scaled && w.block_size != 256 && w.block_size != 32) return false;  // f32 scales per 256- or 32-block
+    if (w.scaled && w.block_size == 32 && w.cols % 256 != 0) return false;
     if (div_ceil(div_ceil(w.cols, 256), (size_t)(w.paired ? 4 : 8)) > (size_t)kRing) return false;  // K range per wave
     return true;
 }
@@ -678,8 +678,9 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.ln_gamma = fu.ln_gamma;
     a.ln_eps = fu.ln_eps;
     a.ln_g = (fu.ln_gamma && w.ln_g && w.ln_gamma_bound == fu.ln_gamma) ? w.ln_g : nullptr;
-    a.wscale = (w.scales && w.block_size == 256) ? w.scales : nullptr;
-    const bool bs32_any = w.scales && w.block_size == 32;
+    a.wscale = (w.scaled && w.block_size == 256) ? w.scales : nullptr;
+    if (w.scaled && w.block_size == 256 && !w.scales) return hipErrorInvalidValue;
+    const bool bs32_any = w.scaled && w.block_size == 32;
     a.stiles = (bs32_any && !w.scales_f16) ? w.scale_tiles : nullptr;
     a.stiles_h = (bs32_any && w.scales_f16) ? w.scale_tiles_h : nullptr;
     a.silu_mul = fu.silu_mul ? 1 : 0;
@@ -802,6 +803,94 @@ __global__ void k_retile_scales_h(const float *__restrict__ scales, int rows, in
     out[i] = __builtin_bit_cast(uint16_t, h);
 }
 
+// ---- the inverse permutations: tiles -> reference layout (transposing the 4 x 4 fields twice is the identity) ----
+__global__ void k_untile(const uint8_t *__restrict__ tiles, size_t row_stride, int rows, int nblk, uint8_t *__restrict__ codes, size_t total16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total16) return;
+    const int lane = (int)(i & 63);
+    const size_t tb = i >> 6;
+    const int blk = (int)(tb % nblk);
+    const size_t tile = tb / nblk;
+    const int row = (int)(16 * tile + (lane & 15));
+    if (row >= rows) return;
+    uint4 v = *reinterpret_cast<const uint4 *>(tiles + i * 16);
+    v.x = transpose_fields(v.x);
+    v.y = transpose_fields(v.y);
+    v.z = transpose_fields(v.z);
+    v.w = transpose_fields(v.w);
+    const size_t off = (size_t)row * row_stride + 64 * blk + 16 * (lane >> 4);
+    if (off + 16 <= (size_t)rows * row_stride) *reinterpret_cast<uint4 *>(codes + off) = v;  // row_stride = nblk * 64 on this path
+}
+template <class T>
+__global__ void k_untile_scales(const T *__restrict__ tiles, int rows, int nblk, float *__restrict__ scales, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i & 1), c = (int)((i >> 1) & 15), kg = (int)((i >> 5) & 3);
+    const size_t tb = i >> 7;
+    const int blk = (int)(tb % nblk);
+    const size_t tile = tb / nblk;
+    const int row = (int)(16 * tile + c);
+    if (row < rows) scales[(size_t)row * nblk * 8 + 8 * blk + 2 * kg + p] = (float)tiles[i];
+}
+
+size_t weights_device_bytes(const Weights &w) {
+    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
+    size_t b = 0;
+    if (w.codes) b += w.rows * w.row_stride_bytes;
+    if (w.scales) b += w.rows * w.nblk * sizeof(float);
+    if (w.tiles) b += n_tiles * nblk * 1024;
+    if (w.scale_tiles) b += n_tiles * nblk * 128 * sizeof(float);
+    if (w.scale_tiles_h) b += n_tiles * nblk * 128 * sizeof(uint16_t);
+    if (w.ln_g) b += w.rows * sizeof(float);
+    return b;
+}
+
+void trim_reference(Weights &w) {
+    std::lock_guard<std::mutex> lk(*w.mu);
+    if (!w.tiles || w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return;  // only what ensure_reference can rebuild
+    if (w.codes) {
+        (void)hipFree(w.codes);
+        w.codes = nullptr;
+    }
+    if (w.scales && w.scaled && w.block_size == 32 && (w.scale_tiles || w.scale_tiles_h)) {
+        (void)hipFree(w.scales);
+        w.scales = nullptr;
+    }
+}
+
+hipError_t ensure_reference(Weights &w, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(*w.mu);
+    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
+    bool built = false;
+    if (!w.codes) {
+        if (!w.tiles) return hipErrorInvalidValue;
+        const size_t bytes = w.rows * w.row_stride_bytes + 16;
+        hipError_t e = hipMalloc((void **)&w.codes, bytes);
+        if (e != hipSuccess) return e;
+        const size_t total16 = n_tiles * nblk * 64;
+        hipLaunchKernelGGL(k_untile, dim3((unsigned)div_ceil(total16, 256)), dim3(256), 0, stream, w.tiles, w.row_stride_bytes, (int)w.rows, (int)nblk,
+                           w.codes, total16);
+        built = true;
+    }
+    if (w.scaled && !w.scales) {
+        if (w.block_size != 32 || !(w.scale_tiles || w.scale_tiles_h)) return hipErrorInvalidValue;
+        hipError_t e = hipMalloc((void **)&w.scales, w.rows * w.nblk * sizeof(float));
+        if (e != hipSuccess) return e;
+        const size_t total = n_tiles * nblk * 128;
+        if (w.scale_tiles_h)
+            hipLaunchKernelGGL(k_untile_scales<_Float16>, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream,
+                               reinterpret_cast<const _Float16 *>(w.scale_tiles_h), (int)w.rows, (int)nblk, w.scales, total);
+        else
+            hipLaunchKernelGGL(k_untile_scales<float>, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, w.scale_tiles, (int)w.rows, (int)nblk,
+                               w.scales, total);
+        built = true;
+    }
+    if (!built) return hipSuccess;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // other threads / streams may use the pointers the moment the lock is gone
+    return e;
+}
+
 hipError_t build_tiles(Weights &w, hipStream_t stream) {
     if (w.scales && w.block_size == 32 && w.scales_f16 && !w.scale_tiles_h) {
         const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
@@ -820,6 +909,7 @@ hipError_t build_tiles(Weights &w, hipStream_t stream) {
                            (int)w.rows, (int)nblk, w.scale_tiles, total);
     }
     if (w.tiles) return hipSuccess;
+    if (!w.codes) return hipErrorInvalidValue;
     const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
     const size_t total16 = n_tiles * nblk * 64;
     hipError_t e = hipMalloc((void **)&w.tiles, total16 * 16);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_gemv_valu(const uint32_t *__restrict__ 
 bool valu_supported(const Weights &w) {
     if (w.row_stride_bytes % 4 != 0) return false;
     if (w.row_stride_bytes * 4 > 16384) return false;  // LDS staging: 64 KiB of f32 at most
-    if (w.scales && (w.block_size % 16 != 0 || w.cols % 16 != 0)) return false;
+    if (w.scaled && (w.block_size % 16 != 0 || w.cols % 16 != 0)) return false;
     return w.rows > 0 && w.cols > 0;
 }
 
@@ -81,7 +81,7 @@ hipError_t launch_gemv_valu(const Weights &w, const float *x, float *y, size_t m
     for (size_t mi = 0; mi < m; ++mi) {
         const float *xr = x + mi * w.cols;
         float *yr = y + mi * w.rows;
-        if (w.scales)
+        if (w.scaled)
             hipLaunchKernelGGL(k_gemv_valu<true>, dim3(grid), dim3(256), lds, stream,
                                (const uint32_t *)w.codes, stride_dw, w.scales, (int)w.nblk,
                                (int)(w.block_size / 16), w.lut, xr, yr, (int)w.rows, (int)w.cols, kpad);

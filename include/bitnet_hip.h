@@ -183,6 +183,13 @@ int bitnet_hip_weights_free(bitnet_hip_weights_t w);
 int bitnet_hip_weights_info(bitnet_hip_weights_t w, size_t *rows, size_t *cols,
                             size_t *algorithmic_bytes);
 
+/* Device memory behind a handle.  The streaming layout (1-KiB code tiles + scale tiles) is the only copy kept: the
+ * reference-layout copy the reference-order kernels (BITNET_HIP_KERNEL_EXACT / _VALU) and the tiled matmul's 32-element
+ * scales read is rebuilt on their first use (exact inverse permutation; that call synchronises its stream once) and stays
+ * until bitnet_hip_weights_trim drops it again.  Nothing a host does concurrently on OTHER handles is affected. */
+size_t bitnet_hip_weights_device_bytes(bitnet_hip_weights_t w);
+int bitnet_hip_weights_trim(bitnet_hip_weights_t w);
+
 /* y_dev[rows] = W . x_dev[cols]   (one activation row: batch-1 decode) */
 int bitnet_hip_gemv_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, void *stream);
 /* Y_dev[m, rows] = X_dev[m, cols] . W^T   (forward_qk256's per-row loop T:683-691,

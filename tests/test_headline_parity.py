@@ -291,3 +291,45 @@ def test_two_host_threads_share_the_library(hip, oracle, torch_):
     for t in ts:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_one_copy_of_the_weights_on_the_device(hip, pkg, oracle, torch_, layer0):
+    """A handle keeps the streaming layout only (both layouts = 2x the model's bytes).  The reference-order
+    kernels rebuild the reference layout on first use -- bit for bit: the exact kernel still equals the scalar oracle --
+    and bitnet_hip_weights_trim drops it again."""
+    cfg, lay = layer0
+    K = cfg.hidden
+    rows = cfg.shapes()["k"][0]
+    h = hip.weights_upload_i2s(lay["k"], lay["k_scales"], rows, K, 32)
+    algo = hip.weights_info(h)[2]
+    assert algo == rows * K // 4 + 2 * rows * K // 32
+    assert hip.weights_device_bytes(h) == algo  # 1 KiB code tiles + f16 scale tiles, nothing else
+    x = np.random.default_rng(8).uniform(-10, 10, K).astype(np.float32)
+    xd = torch_.from_numpy(x).cuda()
+    want = oracle.i2s_matmul(x, lay["k"], lay["k_scales"], 1, rows, K, 32)
+    y = torch_.empty(rows, device="cuda")
+    hip.matmul_kernel_dev(h, xd, y, 1, pkg.KERNEL_EXACT)
+    torch_.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), want)                 # rebuilt codes + scales are the uploaded ones
+    assert hip.weights_device_bytes(h) > 2 * algo                 # reference layout + f32 scales are back
+    hip.weights_trim(h)
+    assert hip.weights_device_bytes(h) == algo
+    hip.matmul_kernel_dev(h, xd, y, 1, pkg.KERNEL_VALU)          # and once more from the trimmed state
+    torch_.cuda.synchronize()
+    assert np.all(approx_eq_with_len(y.cpu().numpy(), want, K))
+    # concat of trimmed parts (tile path) then the exact kernel on the fused matrix
+    h2 = hip.weights_upload_i2s(lay["v"], lay["v_scales"], rows, K, 32)
+    hip.weights_trim(h)
+    hc = hip.weights_concat([h, h2])
+    assert hip.weights_device_bytes(hc) == 2 * algo
+    yc = torch_.empty(2 * rows, device="cuda")
+    hip.matmul_kernel_dev(hc, xd, yc, 1, pkg.KERNEL_EXACT)
+    torch_.cuda.synchronize()
+    want2 = oracle.i2s_matmul(x, lay["v"], lay["v_scales"], 1, rows, K, 32)
+    assert np.array_equal(yc.cpu().numpy(), np.concatenate([want, want2]))
+    # QK256: codes only
+    qs = np.random.default_rng(9).integers(0, 256, rows * K // 4, dtype=np.uint8)
+    hq = hip.weights_upload_qk256(qs, rows, K, K // 4)
+    assert hip.weights_device_bytes(hq) == rows * K // 4
+    for hh in (h, h2, hc, hq):
+        hip.weights_free(hh)
