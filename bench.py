@@ -60,11 +60,11 @@ def build_model(pkg, synth, workload: str, layers_override: int | None):
 
 
 def load_traffic(workload: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass
-    (profiles/traffic_<workload>.json, written by tools/profile_round.sh: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on FETCH_SIZE).
-    PMC counters cannot be read from inside this process, so the figure is the measured one
-    of the profiled build; null when no such file is committed for the workload."""
+    """HBM bytes per launch of the dominant kernel (fused gate|up GEMV) from the committed PMC pass of THIS bench's own launch
+    path: profiles/traffic_<workload>.json, written by tools/profile_round.sh -- separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` runs of `python3 bench.py --workload W --prompt 8 --steps 8` (short: the profiler's counter collection
+    dies past a few tens of thousands of dispatches per process), gfx950 x2 correction on FETCH_SIZE.  PMC counters cannot be
+    read from inside an un-profiled process; null when no file is committed for the workload."""
     path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     try:
         with open(path) as f:

@@ -6,7 +6,11 @@ bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so fe
 2 * FETCH_SIZE * 1024; WRITE_SIZE reads exactly for 16-B-per-lane streaming stores
 (bytes = WRITE_SIZE * 1024).  Other access widths are uncalibrated.
 
-    python tools/profile_summary.py gpurun_out/prof_r01 r01
+    python tools/profile_summary.py gpurun_out/prof_r02/c2 r02 c2
+
+Writes <dir>/summary.{md,json} and, into profiles/: <tag>_<wl>_summary.{md,json}, <tag>_<wl>_kernel_stats.csv (the SAME rows),
+<tag>_<wl>_bench.json (the un-profiled bench line of the same sitting) and traffic_<wl>.json for the workload's dominant I2_S
+GEMV (what bench.py reports as roofline.traffic).  Files of other rounds for that workload are removed.
 """
 import collections
 import csv
@@ -26,8 +30,12 @@ def short(name: str) -> str:
     return (m.group(1) if m else name)[:60]
 
 
+DOMINANT = ("k_gemv_q<8, 5", "k_gemv_mfma<8, 5")  # the fused gate|up GEMV (RING 5: paired matrix at K = 2560)
+
+
 def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
+    wl = sys.argv[3] if len(sys.argv) > 3 else "c2"
     trace = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True)
     k = collections.defaultdict(list)
     grids = collections.defaultdict(set)
@@ -68,7 +76,33 @@ def main():
         f.write("| kernel | WGs | calls | total ms | % | avg us | min | med | max | HBM fetch B/launch | HBM write B/launch |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r in rows:
             f.write("| {kernel} | {workgroups} | {calls} | {total_ms} | {pct} | {avg_us} | {min_us} | {med_us} | {max_us} | {hbm_fetch_bytes_per_launch} | {hbm_write_bytes_per_launch} |\n".format(**r))
-    print(open(os.path.join(out_dir, "summary.md")).read())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    for old in glob.glob(os.path.join(prof, f"r[0-9][0-9]_{wl}_*")) + (glob.glob(os.path.join(prof, "r01_summary.*")) + glob.glob(os.path.join(prof, "r01_kernel_stats.csv")) + glob.glob(os.path.join(prof, "r01_bench_*.json")) if wl == "c2" else []):
+        if not os.path.basename(old).startswith(tag + "_"):
+            os.remove(old)
+    import shutil
+
+    shutil.copy(os.path.join(out_dir, "summary.md"), os.path.join(prof, f"{tag}_{wl}_summary.md"))
+    shutil.copy(os.path.join(out_dir, "summary.json"), os.path.join(prof, f"{tag}_{wl}_summary.json"))
+    if os.path.exists(os.path.join(out_dir, "bench.json")):
+        shutil.copy(os.path.join(out_dir, "bench.json"), os.path.join(prof, f"{tag}_{wl}_bench.json"))
+    with open(os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows)
+    dom = [r for r in rows if r["kernel"].startswith(DOMINANT) and r["hbm_fetch_bytes_per_launch"] is not None]
+    if dom:
+        d = max(dom, key=lambda r: r["total_ms"])
+        with open(os.path.join(prof, f"traffic_{wl}.json"), "w") as f:
+            json.dump({"round": tag, "workload": wl, "kernel": d["kernel"], "workgroups": d["workgroups"],
+                       "hbm_fetch_bytes_per_launch": d["hbm_fetch_bytes_per_launch"], "hbm_write_bytes_per_launch": d["hbm_write_bytes_per_launch"] or 0,
+                       "avg_us_rocprof": d["avg_us"],
+                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `python3 bench.py --workload " + wl +
+                                 " --prompt 8 --steps 8` (the bench's own hipGraph launch path, short run: tools/profile_round.sh says why); "
+                                 "fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024"}, f, indent=1)
+    print(open(os.path.join(out_dir, "summary.md")).read()[:3000])
 
 
 if __name__ == "__main__":
