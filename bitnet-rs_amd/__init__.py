@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -670,6 +671,34 @@ class HostDecoder:
     def run_reference(self, n: int, with_logits: bool = True) -> None:
         """n UNFUSED steps on the bit-exact reference-order kernels (the checker of the fast step; slow)."""
         self._check(self.c.bitnet_host_run_reference(self.h, n, int(with_logits)))
+
+    GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+    def prefill_sharded(self, n: int, rank: int, world: int, gather=None, with_logits: bool = True, digits: int = 3, wire_f16: bool = True,
+                        rccl_comm: int | None = None) -> float:
+        """Token-parallel prefill of the first n fed tokens: this process is `rank` of `world` (one process per GPU).
+        gather(send_ptr, recv_ptr, bytes_per_rank, stream) -> 0 is the all-gather the host supplies (torch.distributed in the
+        tests, see prefill_parallel.torch_gather); rccl_comm (an ncclComm_t as int) takes the C entry
+        bitnet_host_rccl_allgather instead: the path a Rust host would use, no Python per layer."""
+        L = self.c
+        L.bitnet_host_prefill_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        ms = C.c_float(0)
+        if rccl_comm is not None:
+            fn = C.cast(L.bitnet_host_rccl_allgather, C.c_void_p)
+            self._check(L.bitnet_host_prefill_sharded(self.h, n, rank, world, fn, C.c_void_p(rccl_comm), int(with_logits), digits, int(wire_f16), C.byref(ms)))
+            return ms.value
+        cb = None
+        if gather is not None:
+            def _cb(ctx, send, recv, nbytes, stream):
+                try:
+                    return int(gather(send, recv, nbytes, stream) or 0)
+                except Exception as e:  # noqa: BLE001 -- nothing may propagate through the C frames
+                    sys.stderr.write(f"gather callback failed: {e!r}\n")
+                    return -1
+            cb = self.GATHER_FN(_cb)
+        self._check(L.bitnet_host_prefill_sharded(self.h, n, rank, world, C.cast(cb, C.c_void_p) if cb else None, None, int(with_logits), digits,
+                                                  int(wire_f16), C.byref(ms)))
+        return ms.value
 
     def prefill(self, n: int, with_logits: bool = True, digits: int = 4) -> float:
         self.c.bitnet_host_prefill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]

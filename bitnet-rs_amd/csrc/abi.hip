@@ -945,6 +945,36 @@ int bitnet_hip_attention_prefill_sharded_dev(const float *q, size_t ld_q, const 
     BH_GUARD_END
 }
 
+int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const int32_t *q_block_pos, size_t n_q, const void *kv_gathered,
+                                              size_t n_ctx, size_t world, int kv_is_f16, const float *rope_sin, const float *rope_cos,
+                                              float *kcache, float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                              void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    int rc = check_prefill_args(q, kv_gathered, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, n_ctx);
+    if (rc) return rc;
+    if (n_q == 0 || !q_block_pos) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: n_q and q_block_pos must be given");
+    if (world == 0 || n_ctx % (2 * world * 64) != 0)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: context %zu must be a multiple of 2 * world * 64 (world %zu)", n_ctx, world);
+    if (ld_q < n_heads * head_dim) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: row stride too small (ld_q %zu)", ld_q);
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)n_q, (int)n_ctx);
+    if (workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
+    BH_HIP_TRY(launch_attn_prefill(q, (int)ld_q, q_block_pos, (int)n_q, static_cast<const float *>(kv_gathered), (int)(2 * n_kv_heads * head_dim), (int)n_ctx,
+                                   rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes,
+                                   out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_pack_cols_dev(const float *src_dev, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst_dev, int as_f16, void *stream) {
+    BH_GUARD_BEGIN
+    if (!src_dev || !dst_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to pack_cols_dev");
+    if (col0 + ncols > ld) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "pack_cols: columns [%zu, %zu) outside the row stride %zu", col0, col0 + ncols, ld);
+    BH_HIP_TRY(launch_pack_cols(src_dev, ld, col0, ncols, rows, dst_dev, as_f16 ? 1 : 0, (hipStream_t)stream));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 /* K/rocm/attention.rs:54-65: q, k, v, output [batch, num_heads, seq_len, head_dim] row-major f32 (host). */
 int bitnet_hip_attention(const float *q, size_t q_len, const float *k, size_t k_len, const float *v, size_t v_len, float *output,
                          size_t out_len, size_t seq_len, size_t num_heads, size_t head_dim, int causal, float scale) {

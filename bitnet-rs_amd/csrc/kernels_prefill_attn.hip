@@ -48,7 +48,21 @@ struct PrefillArgs {
     int n_heads, n_kv, max_pos, T, Tpad;  // T = context tokens (keys)
     _Float16 *qh, *kh, *vt;  // workspace: q [head][nq_pad][128], k [kv][Tpad][128], v^T [kv][128][Tpad]
     float *out;              // [nq, heads * 128]
+    // token-parallel prefill: the k|v rows as the all-gather left them, [rank][that rank's two zigzag chunks] -- the row
+    // of absolute position t is found here instead of by a scatter pass on the host side.  zz_world == 0: absolute order.
+    int zz_world, zz_chunk;  // ranks, tokens per chunk (T = 2 * world * chunk; chunk % 64 == 0)
+    int kv_f16;              // the k|v rows travelled as f16 (half the bytes on the wire); k / v then point at _Float16
 };
+
+// row of absolute position t (a multiple of 64) in the gathered k|v buffer: chunk c = t / chunk belongs to rank c (first
+// half of the chunks) or 2 world - 1 - c (second half), as that rank's first or second chunk
+__device__ __forceinline__ int zz_row(const PrefillArgs &p, int t) {
+    if (p.zz_world == 0) return t;
+    const int c = t / p.zz_chunk, off = t - c * p.zz_chunk;
+    const bool first = c < p.zz_world;
+    const int r = first ? c : 2 * p.zz_world - 1 - c;
+    return r * 2 * p.zz_chunk + (first ? 0 : p.zz_chunk) + off;
+}
 
 // grid (max(nq_pad, Tpad) / 64, heads + 2 kv): slot < heads: query head (rows of p.q, positions from
 // q_block_pos); then k heads, then v heads (rows of p.kv, position = row).
@@ -63,9 +77,18 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     const int ld = is_q ? p.ld_q : p.ld_kv;
     // absolute position of row t0 (padding blocks past the last real one hold zeros: any position will do)
     const int pos0 = is_q && p.q_block_pos ? ((int)blockIdx.x < (p.nq + kQB - 1) / kQB ? p.q_block_pos[blockIdx.x] : 0) : t0;
-    for (int i = 0; i < 32; ++i) {
-        const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
-        tile[tok][d] = t0 + tok < n_rows ? src[(size_t)(t0 + tok) * ld + d] : 0.0f;
+    const int r0 = is_q ? t0 : zz_row(p, t0);  // a 64-row block of positions is 64 consecutive gathered rows (chunk % 64 == 0)
+    if (!is_q && p.kv_f16) {
+        const _Float16 *sh = reinterpret_cast<const _Float16 *>(p.k) + (size_t)(slot - p.n_heads) * p.hs_kv;  // k heads then v heads
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+            tile[tok][d] = t0 + tok < n_rows ? (float)sh[(size_t)(r0 + tok) * ld + d] : 0.0f;
+        }
+    } else {
+        for (int i = 0; i < 32; ++i) {
+            const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+            tile[tok][d] = t0 + tok < n_rows ? src[(size_t)(r0 + tok) * ld + d] : 0.0f;
+        }
     }
     __syncthreads();
     if ((is_q || is_k) && p.rope) {
@@ -264,13 +287,18 @@ size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
 // (null: 64 b); kv: T context rows in absolute order (stride ld_kv: k heads then v heads).
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
-                               int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream) {
+                               int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream,
+                               int zz_world, int kv_f16) {
     if (D != kPD || T <= 0 || nq <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
+    if (zz_world < 0 || (zz_world > 0 && (T % (2 * zz_world * kQB) != 0))) return hipErrorInvalidValue;
     if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, nq, T)) return hipErrorInvalidValue;
     PrefillArgs p;
     p.q = q;
     p.k = kv;
-    p.v = kv + (size_t)n_kv * kPD;
+    p.v = kv + (size_t)n_kv * kPD;  // (f16 rows: the prep kernel indexes k heads then v heads from p.k itself)
+    p.zz_world = zz_world;
+    p.zz_chunk = zz_world > 0 ? T / (2 * zz_world) : 0;
+    p.kv_f16 = kv_f16;
     p.ld_q = ld_q;
     p.ld_kv = ld_kv;
     p.hs_q = p.hs_kv = kPD;
@@ -302,6 +330,25 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     return hipGetLastError();
 }
 
+// rows x [col0, col0 + ncols) of a row-major f32 matrix -> a compact [rows, ncols] buffer, f32 or f16: the k|v columns of the
+// q|k|v projection as one contiguous send buffer for the token-parallel prefill's all-gather
+__global__ void k_pack_cols(const float *__restrict__ src, size_t ld, size_t col0, size_t ncols, size_t total, void *__restrict__ dst, int f16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t r = i / ncols, c = i - r * ncols;
+    const float v = src[r * ld + col0 + c];
+    if (f16)
+        static_cast<_Float16 *>(dst)[i] = (_Float16)v;
+    else
+        static_cast<float *>(dst)[i] = v;
+}
+hipError_t launch_pack_cols(const float *src, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst, int f16, hipStream_t stream) {
+    const size_t total = rows * ncols;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, src, ld, col0, ncols, total, dst, f16);
+    return hipGetLastError();
+}
+
 // Plain multi-head attention over caller tensors [heads][seq][128] (no RoPE, no cache): the shape of
 // the reference's fused_attention_hip stub (K/rocm/attention.rs:54-65), one batch element.
 hipError_t launch_attn_generic(const float *q, const float *k, const float *v, float *out, int n_heads, int seq, int causal,
@@ -320,6 +367,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.causal = causal;
     p.scale = scale;
     p.q_block_pos = nullptr;
+    p.zz_world = p.zz_chunk = p.kv_f16 = 0;
     p.nq = seq;
     p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -156,7 +158,8 @@ Decoder::~Decoder() {
                     (void *)qkv_, (void *)att_, (void *)h_, (void *)ref_n_, (void *)ref_gu_, (void *)ref_t_, qa_x_, qa_x2_, qa_att_, qa_h_, (void *)st_x_, (void *)st_x2_, (void *)logits_, scratch_, (void *)attn_scratch_, (void *)pos_, (void *)n_forced_,
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
-    for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
+    for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_, sp_kv_send_, sp_kv_all_,
+                    (void *)sp_block_pos_, (void *)sp_tokens_})
         if (p) hipFree(p);
     if (stream_) hipStreamDestroy((hipStream_t)stream_);
 }
@@ -568,12 +571,13 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
     }
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
-    if (n > pf_cap_) {
+    if (n > pf_cap_ || bitnet_hip_attention_prefill_workspace_bytes((size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)n) > pf_attn_ws_bytes_) {
         for (void *q : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_})
             if (q) hipFree(q);
         pf_x_ = pf_qkv_ = pf_att_ = pf_h_ = nullptr;
         pf_gemm_ws_ = pf_attn_ws_ = nullptr;
         pf_cap_ = 0;
+        pf_attn_ws_bytes_ = 0;
         const size_t N = (size_t)n;
         pf_gemm_ws_bytes_ = bitnet_hip_matmul_workspace_bytes(N, H > F ? H : F, 4);
         pf_attn_ws_bytes_ = bitnet_hip_attention_prefill_workspace_bytes((size_t)c_.n_heads, (size_t)c_.n_kv_heads, N);
@@ -610,6 +614,123 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     HCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return 0;
+}
+
+int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, bool with_logits, int digits,
+                             bool wire_f16, float *elapsed_ms) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) {
+        err_ = "prefill_sharded: bad rank / world / gather";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (n <= 0 || n % (2 * world * 64) != 0) {
+        char b[128];
+        snprintf(b, sizeof(b), "prompt length %d must be a positive multiple of %d (2 * world * 64) for world %d", n, 2 * world * 64, world);
+        err_ = b;
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    if (p != 0) {
+        err_ = "prefill needs a fresh sequence (position 0): reset() first";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (n > host_forced_) {
+        err_ = "prefill: feed() the prompt tokens first";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (n > c_.max_pos - 1) {
+        err_ = "KV cache overflow";  // T:1190-1194
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
+    const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
+    const int chunk = n / (2 * world), nq = 2 * chunk;
+    const size_t N = (size_t)nq, esz = wire_f16 ? 2 : 4;
+    if (nq > pf_cap_) {  // the per-row buffers of the unsharded prefill, sized for this rank's rows
+        for (void *q : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_})
+            if (q) hipFree(q);
+        pf_x_ = pf_qkv_ = pf_att_ = pf_h_ = nullptr;
+        pf_gemm_ws_ = nullptr;
+        pf_cap_ = 0;
+        pf_gemm_ws_bytes_ = bitnet_hip_matmul_workspace_bytes(N, H > F ? H : F, 4);
+        HCHK(dalloc(&pf_x_, N * H));
+        HCHK(dalloc(&pf_qkv_, N * (QD + 2 * KD)));
+        HCHK(dalloc(&pf_att_, N * QD));
+        HCHK(dalloc(&pf_h_, N * F));
+        HCHK(hipMalloc(&pf_gemm_ws_, pf_gemm_ws_bytes_));
+        pf_cap_ = nq;
+    }
+    const size_t awb = bitnet_hip_attention_prefill_sharded_workspace_bytes(NH, NK, N, (size_t)n);
+    if (awb > pf_attn_ws_bytes_) {
+        if (pf_attn_ws_) hipFree(pf_attn_ws_);
+        pf_attn_ws_ = nullptr;
+        pf_attn_ws_bytes_ = 0;
+        HCHK(hipMalloc(&pf_attn_ws_, awb));
+        pf_attn_ws_bytes_ = awb;
+    }
+    if (nq > sp_cap_ || n > sp_ctx_) {
+        for (void *q : {sp_kv_send_, sp_kv_all_, (void *)sp_block_pos_, (void *)sp_tokens_})
+            if (q) hipFree(q);
+        sp_kv_send_ = sp_kv_all_ = nullptr;
+        sp_block_pos_ = sp_tokens_ = nullptr;
+        sp_cap_ = sp_ctx_ = 0;
+        HCHK(hipMalloc(&sp_kv_send_, N * 2 * KD * 4));
+        HCHK(hipMalloc(&sp_kv_all_, (size_t)n * 2 * KD * 4));
+        HCHK(dalloc(&sp_block_pos_, N / 64));
+        HCHK(dalloc(&sp_tokens_, N));
+        sp_cap_ = nq;
+        sp_ctx_ = n;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    {
+        // this rank's rows: chunk `rank`, then chunk 2 world - 1 - rank
+        std::vector<int32_t> hist((size_t)n), tok(N), bp(N / 64);
+        HCHK(hipMemcpy(hist.data(), history_, (size_t)n * 4, hipMemcpyDeviceToHost));
+        const int starts[2] = {rank * chunk, (2 * world - 1 - rank) * chunk};
+        for (int h = 0; h < 2; ++h)
+            for (int i = 0; i < chunk; ++i) {
+                tok[(size_t)h * chunk + i] = hist[(size_t)starts[h] + i];
+                if (i % 64 == 0) bp[((size_t)h * chunk + i) / 64] = starts[h] + i;
+            }
+        HCHK(hipMemcpy(sp_tokens_, tok.data(), N * 4, hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(sp_block_pos_, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    }
+    Event ev0, ev1;
+    HCHK(hipEventCreate(&ev0.e));
+    HCHK(hipEventCreate(&ev1.e));
+    HCHK(hipEventRecord(ev0.e, s));
+    BCHK(bitnet_hip_embed_f16_dev(embed_, sp_tokens_, nullptr, N, H, (size_t)c_.vocab, pf_x_, s));
+    const size_t ld = QD + 2 * KD, per_rank = N * 2 * KD * esz;
+    for (auto &L : layers_) {
+        BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        // the raw (pre-RoPE) k|v rows this rank contributes, compact, f32 or f16
+        BCHK(bitnet_hip_pack_cols_dev(pf_qkv_, ld, QD, 2 * KD, N, world > 1 ? sp_kv_send_ : sp_kv_all_, wire_f16 ? 1 : 0, s));
+        if (world > 1 && gather(gather_ctx, sp_kv_send_, sp_kv_all_, per_rank, s) != 0) {
+            err_ = "prefill_sharded: the all-gather callback failed";
+            return BITNET_HIP_ERR_EXECUTION;
+        }
+        BCHK(bitnet_hip_attention_prefill_gathered_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
+                                                       rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
+                                         pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+    }
+    {
+        // the last prompt position sits in chunk 2 world - 1 = rank 0's second chunk: its last local row
+        const int rc = finish_prefill(n, rank == 0 ? pf_x_ + (N - 1) * H : nullptr, with_logits);
+        if (rc) return rc;
+    }
+    HCHK(hipEventRecord(ev1.e, s));
+    HCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, ev0.e, ev1.e));
     if (elapsed_ms) *elapsed_ms = ms;
     return 0;
 }
@@ -829,6 +950,21 @@ int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elaps
 }
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->prefill(n, with_logits != 0, digits, elapsed_ms);
+}
+int bitnet_host_prefill_sharded(void *d, int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, int with_logits,
+                                int digits, int wire_f16, float *elapsed_ms) {
+    return static_cast<Decoder *>(d)->prefill_sharded(n, rank, world, gather, gather_ctx, with_logits != 0, digits, wire_f16 != 0, elapsed_ms);
+}
+int bitnet_host_rccl_allgather(void *nccl_comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream) {
+    // ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
+    using fn_t = int (*)(const void *, void *, size_t, int, void *, void *);
+    static fn_t fn = [] {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        return h ? reinterpret_cast<fn_t>(dlsym(h, "ncclAllGather")) : nullptr;
+    }();
+    if (!fn || !nccl_comm) return -1;
+    return fn(send_dev, recv_dev, bytes_per_rank, /* ncclUint8 */ 1, nccl_comm, stream);
 }
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits) {
     return static_cast<Decoder *>(d)->finish_prefill(n, last_row, with_logits != 0);

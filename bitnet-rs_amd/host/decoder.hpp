@@ -18,6 +18,12 @@
 
 #include "bitnet_hip.h"
 
+extern "C" {
+// The collective of the token-parallel prefill as the host supplies it: gather `bytes_per_rank` bytes from every rank into
+// recv ([world][bytes_per_rank], rank order), ordered on `stream` (a hipStream_t) like a kernel launch.  0 = success.
+typedef int (*bitnet_host_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream);
+}
+
 namespace bitnet_host {
 
 // ModelConfig fields the path needs (crates/bitnet-common/src/config.rs:25-46; GGUF keys
@@ -92,6 +98,13 @@ class Decoder {
     // with_logits samples the token after the prompt exactly as run() does for the last
     // prompt position.  digits: fixed-point digits per activation in the matmuls (2..4).
     int prefill(int n, bool with_logits, int digits, float *elapsed_ms);
+    // Token-parallel prefill of ONE long prompt over `world` GPUs, one process per GPU (BASELINE configs[4]):
+    // this rank runs the first n fed tokens' zigzag chunks rank and 2 world - 1 - rank through every layer (weights are
+    // replicated: all seven projections are collective-free); per layer ONE all-gather of the raw k|v rows through
+    // `gather` (RCCL: bitnet_host_rccl_allgather; tests: any callable), after which every rank fills its own KV cache
+    // for all n positions.  n % (2 * world * 64) == 0.  wire_f16: k|v travel as f16.
+    int prefill_sharded(int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, bool with_logits, int digits,
+                        bool wire_f16, float *elapsed_ms);
     // Tail of a prefill driven from outside (token-parallel prefill, bitnet-rs_amd/prefill_parallel.py):
     // the KV cache already holds positions 0..n-1; last_row (device, [hidden]) is the residual stream
     // of position n-1 or null on ranks that do not own it (then only the position counter moves).
@@ -150,6 +163,10 @@ class Decoder {
     float *attn_scratch_ = nullptr;
     int32_t *pos_ = nullptr, *n_forced_ = nullptr, *history_ = nullptr, *token_ = nullptr;
     int host_forced_ = 0;
+    // sharded prefill buffers (grown on demand)
+    int sp_cap_ = 0, sp_ctx_ = 0;
+    void *sp_kv_send_ = nullptr, *sp_kv_all_ = nullptr;
+    int32_t *sp_block_pos_ = nullptr, *sp_tokens_ = nullptr;
     // prefill buffers (grown on demand)
     int pf_cap_ = 0;
     float *pf_x_ = nullptr, *pf_qkv_ = nullptr, *pf_att_ = nullptr, *pf_h_ = nullptr;
@@ -187,6 +204,11 @@ int bitnet_host_set_act_mode(void *d, int mode);
 int bitnet_host_act_mode(void *d);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);
+int bitnet_host_prefill_sharded(void *d, int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, int with_logits,
+                                int digits, int wire_f16, float *elapsed_ms);
+// ncclAllGather on an existing RCCL communicator (ctx = ncclComm_t), resolved from librccl.so at first use: the host library
+// itself does not link RCCL.  Pass it as `gather` with the communicator as gather_ctx.
+int bitnet_host_rccl_allgather(void *nccl_comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream);
 void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4);
 void bitnet_host_global_objects(void *d, void **ptrs7);
 int bitnet_host_position(void *d);

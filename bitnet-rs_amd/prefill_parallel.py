@@ -146,3 +146,35 @@ class TokenParallelPrefill:
                 recv.copy_(send)
             self.layer_back(l, recv.view(self.world, self.nq, 2 * self.KD))
         self.finish(with_logits)
+
+
+# ---- the collective for Decoder::prefill_sharded (C++ host loop, bitnet-rs_amd/host/decoder.cpp) ---------------------------
+
+class _DevBytes:
+    """__cuda_array_interface__ view of raw device memory, so torch can wrap the host loop's buffers."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def torch_gather(world: int):
+    """gather(send_ptr, recv_ptr, bytes_per_rank, stream) over torch.distributed (backend nccl = RCCL, or gloo in the
+    one-GPU rehearsals): the device buffers are the C++ loop's own.  Host-synchronises around the collective (torch's
+    communicator streams are not the decoder's); the pure-C path (rccl.py + bitnet_host_rccl_allgather) has no such stop."""
+    import torch
+    import torch.distributed as dist
+
+    def gather(send, recv, nbytes, stream):
+        torch.cuda.synchronize()  # the pack kernel on the decoder's stream
+        s = torch.as_tensor(_DevBytes(send, nbytes), device="cuda")
+        r = torch.as_tensor(_DevBytes(recv, nbytes * world), device="cuda")
+        if dist.get_backend() == "gloo":  # host-staged
+            rc = torch.empty(nbytes * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(rc, s.cpu())
+            r.copy_(rc)
+        else:
+            dist.all_gather_into_tensor(r, s)
+        torch.cuda.synchronize()
+        return 0
+
+    return gather

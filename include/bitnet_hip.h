@@ -384,6 +384,20 @@ int bitnet_hip_attention_prefill_sharded_dev(const float *q_dev, size_t ld_q, co
                                              size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                              void *workspace_dev, size_t workspace_bytes, float *out_dev,
                                              void *stream);
+/* The same with the k|v rows exactly as an all-gather over `world` ranks left them: rank r's block holds its two zigzag
+ * chunks (chunk c of 2 * world equal chunks belongs to rank c or 2 * world - 1 - c: every rank gets the same amount of
+ * causal attention), each row = k heads then v heads, f32 or -- kv_is_f16 -- f16 (half the bytes on the wire; the f32 decode
+ * cache then holds the f16-rounded k, v of the prompt).  No scatter pass on the host side: the position -> row map is
+ * applied where the rows are read.  n_ctx % (2 * world * 64) == 0.  bitnet_hip_pack_cols_dev builds the send buffer: the
+ * columns [col0, col0 + ncols) of `rows` f32 rows, compact, as f32 or f16. */
+int bitnet_hip_attention_prefill_gathered_dev(const float *q_dev, size_t ld_q, const int32_t *q_block_pos_dev, size_t n_q,
+                                              const void *kv_gathered_dev, size_t n_ctx, size_t world, int kv_is_f16,
+                                              const float *rope_sin_dev, const float *rope_cos_dev, float *kcache_dev,
+                                              float *vcache_dev, size_t n_heads, size_t n_kv_heads, size_t head_dim,
+                                              size_t max_pos, void *workspace_dev, size_t workspace_bytes, float *out_dev,
+                                              void *stream);
+int bitnet_hip_pack_cols_dev(const float *src_dev, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst_dev,
+                             int as_f16, void *stream);
 /* bytes of scratch_dev attention_decode_dev needs (per-chunk softmax partials) */
 size_t bitnet_hip_attention_scratch_bytes(size_t n_kv_heads, size_t max_pos);
 /* TransformerModel::logits, tied embeddings (T:1599-1630): logits = LN(x) . E^T, E the f16

@@ -302,3 +302,75 @@ def test_decode_switches_to_the_wide_attention_form(pkg, oracle, synth):
     assert dec.position() == n_prompt + n_new - 1
     dec.close()
     om.close()
+
+
+@pytest.mark.parametrize("world,T,wire_f16", [(1, 128, False), (2, 256, False), (2, 512, True)])
+def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T, wire_f16):
+    """Decoder::prefill_sharded (the C++ host loop + bitnet_hip_attention_prefill_gathered_dev: zigzag chunks, k|v rows read
+    in place from the gathered buffer) with `world` decoders = ranks on ONE GPU, each driven from its own host thread, the
+    all-gather supplied as a callback that meets at a barrier -- against the unsharded Decoder.prefill."""
+    import threading
+
+    cfg = synth.ModelConfig(**dict(SMALL, max_pos=640))
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    prompt = synth.prompt(T, cfg.vocab)
+
+    def make():
+        d = pkg.HostDecoder(cfg)
+        for l, w in enumerate(layers):
+            d.set_layer_qk256(l, w)
+        d.set_globals(glob)
+        d.reset()
+        d.feed(prompt)
+        return d
+
+    ref = make()
+    ref.prefill(T, with_logits=True, digits=3)
+    want_logits = ref.last_logits()
+    ref.run(3, with_logits=True)
+    want_tokens = list(ref.history(T + 4))
+    ref.close()
+    decs = [make() for _ in range(world)]
+    slots, bar, errors = [None] * world, threading.Barrier(world), []
+
+    def gather_for(rank):
+        def gather(send, recv, nbytes, stream):
+            torch_.cuda.synchronize()
+            tp_mod = importlib.import_module("bitnet-rs_amd.prefill_parallel")
+            slots[rank] = torch_.as_tensor(tp_mod._DevBytes(send, nbytes), device="cuda").clone()
+            bar.wait(timeout=60)
+            r = torch_.as_tensor(tp_mod._DevBytes(recv, nbytes * world), device="cuda")
+            r.copy_(torch_.cat(slots))
+            torch_.cuda.synchronize()
+            bar.wait(timeout=60)
+            return 0
+        return gather
+
+    def run(rank):
+        try:
+            decs[rank].prefill_sharded(T, rank, world, gather_for(rank) if world > 1 else None, with_logits=True, digits=3, wire_f16=wire_f16)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    d0 = decs[0]
+    assert d0.position() == T
+    got = d0.last_logits()
+    # f16 on the wire rounds the prompt's k|v in the decode cache (not in the prompt attention, which is f16 either way)
+    assert cosine(got, want_logits) >= 0.999999 and np.max(np.abs(got - want_logits)) <= 1e-3 * np.max(np.abs(want_logits))
+    d0.run(3, with_logits=True)  # decode continues on the cache the shards filled -- on every rank
+    assert list(d0.history(T + 4)) == want_tokens or wire_f16
+    for d in decs[1:]:
+        assert d.position() == T
+    for d in decs:
+        d.close()
+    with pytest.raises(pkg.BitNetHipError, match="multiple of"):
+        dd = make()
+        dd.prefill_sharded(100, 0, 2, lambda *a: 0)

@@ -22,9 +22,10 @@ import sys
 
 
 def short(name: str) -> str:
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"(?:bitnet_hip::)?([A-Za-z0-9_]+(?:<[^(]*>)?)", name)
     if name.startswith("_ZN10bitnet_hip"):
+        name = name.replace("12_GLOBAL__N_1", "")
         m2 = re.match(r"_ZN10bitnet_hip\d+([a-z_0-9A-Z]+?)(?:I|E)", name)
         return m2.group(1) if m2 else name[:40]
     return (m.group(1) if m else name)[:60]
