@@ -164,47 +164,74 @@ def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
             "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
-def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
-    """BASELINE configs[4]: one 8k-token prompt, token-parallel over the ranks (zigzag chunks,
-    replicated weights, ONE all-gather of k|v per layer over RCCL; bitnet-rs_amd/prefill_parallel.py).
-    A step = the whole prompt forward incl. the first sampled token; value = prompt tokens/s."""
+def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps: int, warmup: int):
+    """BASELINE configs[4]: ONE long prompt, token-parallel over the ranks (zigzag chunks, replicated weights, one all-gather
+    of the k|v rows per layer; Decoder::prefill_sharded, bitnet-rs_amd/host/decoder.cpp).  The collective is RCCL over xGMI
+    through the C entry bitnet_host_rccl_allgather on a communicator created here (bitnet-rs_amd/rccl.py) -- the path a Rust
+    host takes, no Python between the layers; with BITNET_DIST_BACKEND=gloo (one-GPU rehearsals) torch.distributed carries it.
+    A step = the whole prompt forward incl. the first sampled token.  Returns the result object (rank 0) or None."""
     import torch
 
     tp_mod = importlib.import_module("bitnet-rs_amd.prefill_parallel")
-    prompt = synth.prompt(PROMPT_LEN, cfg.vocab)
-    tp = tp_mod.TokenParallelPrefill(dec, hip, r.rank, r.world, digits=args.digits)
+    prompt = synth.prompt(prompt_len, cfg.vocab)
+    comm, gather, how = None, None, "none (1 GPU)"
+    if r.world > 1:
+        if r.backend == "nccl":
+            try:
+                rccl = importlib.import_module("bitnet-rs_amd.rccl")
+                comm = rccl.Comm(r.rank, r.world)
+                how = "ncclAllGather (RCCL over xGMI) from the C++ host loop"
+            except Exception as e:  # noqa: BLE001 -- a second communicator could not be created: torch's own carries the gather
+                comm = None
+                sys.stderr.write(f"rank {r.rank}: own RCCL communicator failed ({e!r}); using torch.distributed's\n")
+        if comm is None:
+            gather = tp_mod.torch_gather(r.world)
+            how = f"torch.distributed all_gather_into_tensor ({r.backend}, host-synchronised)"
 
     def one():
         dec.reset()
         dec.feed(prompt)
-        tp.run(prompt, with_logits=True)
+        dec.prefill_sharded(prompt_len, r.rank, r.world, gather=gather, with_logits=True, digits=args.digits, wire_f16=True,
+                            rccl_comm=comm.handle if comm else None)
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         one()
-    steps = args.steps
     elapsed = dist_.timed_region(r, lambda: [one() for _ in range(steps)])
-    token = int(dec.history(PROMPT_LEN + 1)[PROMPT_LEN]) if r.rank == 0 else -1
+    seen = 1
+    if r.world > 1:
+        import torch.distributed as dist
+
+        t = torch.ones(1, device="cuda" if r.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+    token = int(dec.history(prompt_len + 1)[prompt_len]) if r.rank == 0 else -1
+    if comm:
+        comm.close()
+    if r.rank != 0:
+        return None
+    flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * prompt_len + 4.0 * prompt_len * prompt_len / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
+    kv_bytes = prompt_len * 2 * cfg.n_kv_heads * cfg.head_dim * 2
+    return {
+        "workload": f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {r.world}xMI355X token-parallel prefill, {prompt_len}-token prompt",
+        "tokens": prompt_len, "steps": steps, "ms_per_prompt": round(elapsed / steps * 1e3, 3), "tokens_per_s": round(prompt_len * steps / elapsed, 1),
+        "eff_TFLOPs": round(flops * steps / elapsed / 1e12, 1), "digits": args.digits, "ranks_seen": seen, "first_sampled_token": token,
+        "parallelism": f"token-parallel x{r.world} (zigzag chunks), weights replicated",
+        "collective": f"all-gather of k|v rows (f16 on the wire) per layer: {kv_bytes} B x {cfg.n_layers} layers; {how}" if r.world > 1 else how,
+        "scaling": "strong",
+    }
+
+
+def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
+    """`--workload c5` on its own: the prefill line as THE json line."""
+    res = sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, PROMPT_LEN, args.steps, args.warmup)
     if r.rank == 0:
-        flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
-        kv_bytes = PROMPT_LEN * 2 * cfg.n_kv_heads * cfg.head_dim * 4
         out = {
             "metric": "prefill tokens/sec, bitnet-b1.58-2B-4T, one prompt token-parallel over the GPUs",
-            "value": round(PROMPT_LEN * steps / elapsed, 1),
-            "unit": "tokens/s",
-            "n_gpus": r.world,
-            "steps": steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
+            "value": res["tokens_per_s"], "unit": "tokens/s", "n_gpus": r.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_prompt"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": f"i8 MFMA on {args.digits}-digit fixed-point activations (projections), f16 MFMA (attention), f32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {r.world}xMI355X token-parallel prefill, {PROMPT_LEN}-token prompt",
-                       "layers": cfg.n_layers, "parallelism": f"token-parallel x{r.world} (zigzag chunks), weights replicated",
-                       "collective": f"all-gather of k|v per layer: {kv_bytes} B x {cfg.n_layers} layers" if r.world > 1 else "none (1 GPU)"},
-            "eff_TFLOPs": round(flops * steps / elapsed / 1e12, 1),
-            "first_sampled_token": token,
+            "data": "synthetic", "config": {"workload": res["workload"], "layers": cfg.n_layers, "parallelism": res["parallelism"], "collective": res["collective"]},
+            "eff_TFLOPs": res["eff_TFLOPs"], "first_sampled_token": res["first_sampled_token"], "ranks_seen": res["ranks_seen"],
         }
         print(json.dumps(out), flush=True)
     dec.close()
@@ -222,6 +249,8 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
+    ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the token-parallel prefill that normally rides in the same line")
+    ap.add_argument("--c5-prompt", type=int, default=8192, help="prompt length of that prefill (a multiple of 128 x N)")
     ap.add_argument("--exact-act", action="store_true", help="exact f32 activations between the kernels (round 1's path) instead of QAct")
     args = ap.parse_args()
 
@@ -367,6 +396,17 @@ def main():
                               "note": "whole-prompt forward incl. first sampled token; I2_S projections on i8 MFMA digit planes, attention on f16 MFMA"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
+    # N > 1: the decode line above is N independent replicas (batch-1 decode does not shard); the path's ONE real collective
+    # -- the token-parallel prefill of BASELINE configs[4] -- runs here too, over the same ranks, and rides in the same line
+    c5 = None
+    if n_gpus > 1 and args.workload in ("c2", "c3") and not args.no_c5:
+        dec.close()
+        cfg5, dec5, _ = build_model(pkg, synth, "c5", args.layers)
+        c5 = sharded_prefill(args, pkg, synth, dist_, r, cfg5, dec5, args.c5_prompt, 2, 1)
+        dec = dec5
+    if rank == 0:
+        if c5 is not None:
+            out["prefill_c5"] = c5
         print(json.dumps(out), flush=True)
     dec.close()
     dist_.finalize(r)
