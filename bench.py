@@ -38,7 +38,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy 
 PROMPT_LEN = 128
 
 
-def build_model(pkg, synth, workload: str, layers_override: int | None):
+def build_model_from_gguf(pkg, synth, path: str, max_pos: int):
+    """A real model file (e.g. microsoft/bitnet-b1.58-2B-4T-gguf ggml-model-i2_s.gguf, 1,187,801,280 B, sha256 4221b252...,
+    docs/baselines/ggml-model-i2_s.fingerprint) through the product loader: bitnet-rs_amd/host/gguf.cpp mmaps it, takes the
+    configuration from its metadata and uploads every I2_S projection in its on-disk flavour.  Path: --gguf or $BITNET_GGUF."""
+    f = pkg.GgufFile(path=path)
+    c = f.config()
+    cfg = synth.ModelConfig(hidden=c["hidden"], n_layers=c["n_layers"], n_heads=c["n_heads"] or 20, n_kv_heads=c["n_kv_heads"] or c["n_heads"] or 5,
+                            head_dim=c["hidden"] // (c["n_heads"] or 20), ffn=c["ffn"], vocab=c["vocab"], max_pos=max_pos,
+                            eps=c["eps"] if c["eps"] is not None else 1e-5, rope_theta=c["rope_theta"] if c["rope_theta"] is not None else 10000.0)
+    dec = pkg.HostDecoder(cfg)
+    dec.load_gguf(f)
+    f.close()
+    return cfg, dec, None
+
+
+def build_model(pkg, synth, workload: str, layers_override: int | None, gguf: str | None = None):
+    if gguf:
+        return build_model_from_gguf(pkg, synth, gguf, 4736 if workload == "c4" else 8256 if workload == "c5" else 1024)
     cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
     if layers_override:
         cfg.n_layers = layers_override
@@ -249,6 +266,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
+    ap.add_argument("--gguf", default=None, help="a real model file instead of synthetic weights (default: $BITNET_GGUF if set); the line then says data: gguf")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the token-parallel prefill that normally rides in the same line")
     ap.add_argument("--c5-prompt", type=int, default=8192, help="prompt length of that prefill (a multiple of 128 x N)")
     ap.add_argument("--exact-act", action="store_true", help="exact f32 activations between the kernels (round 1's path) instead of QAct")
@@ -287,7 +305,8 @@ def main():
 
     global PROMPT_LEN
     PROMPT_LEN = args.prompt or {"c4": 4096, "c5": 8192}.get(args.workload, 128)
-    cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers)
+    gguf = args.gguf or os.environ.get("BITNET_GGUF")
+    cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers, gguf)
     if args.exact_act:
         dec.set_act_mode(0)
     if args.workload == "c5":
@@ -367,7 +386,7 @@ def main():
             "dtype": ("i8 MFMA on producer-quantised activations (QAct: 15-bit fixed point per element, one power-of-two scale per 16), exact integer "
                       "partial sums, f32 accumulate / f32 elsewhere (f16 embedding table)") if dec.act_mode() else
                      "i8 MFMA on exact 30-bit fixed-point activations, f32 accumulate / f32 elsewhere (f16 embedding table)",
-            "data": "synthetic",
+            "data": f"gguf:{os.path.basename(gguf)}" if gguf else "synthetic",
             "config": {
                 "workload": f"bitnet-b1.58-2B-4T I2_S BitNet32-F16 (ternary, one f16 scale per 32 weights), {n_gpus}xMI355X, batch=1 decode, {PROMPT_LEN}-token prompt"
                 if args.workload == "c2"

@@ -475,6 +475,17 @@ def declared_symbols() -> list[str]:
 HOST_LIB_PATH = os.path.join(HERE, "libbitnet_host.so")
 
 
+def blake3_hex(data: bytes) -> str:
+    """BLAKE3 as the trace records carry it (host/blake3.hpp)."""
+    load()
+    L = C.CDLL(HOST_LIB_PATH)
+    L.bitnet_host_blake3_hex.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    out = C.create_string_buffer(65)
+    if L.bitnet_host_blake3_hex(data, len(data), out) != 0:
+        raise BitNetHipError(ERR_INVALID_ARGUMENT, "blake3_hex failed")
+    return out.value.decode()
+
+
 class HostConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "ffn", "vocab", "max_pos")] + [
         ("eps", C.c_float),
@@ -667,6 +678,12 @@ class HostDecoder:
 
     def act_mode(self) -> int:
         return int(self.c.bitnet_host_act_mode(self.h))
+
+    def trace_step(self, directory: str, with_logits: bool = True) -> None:
+        """One eager step leaving the reference's per-tensor trace records (crates/bitnet-trace) in `directory`."""
+        self.c.bitnet_host_trace_step.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        os.makedirs(directory, exist_ok=True)
+        self._check(self.c.bitnet_host_trace_step(self.h, directory.encode(), int(with_logits)))
 
     def run_reference(self, n: int, with_logits: bool = True) -> None:
         """n UNFUSED steps on the bit-exact reference-order kernels (the checker of the fast step; slow)."""

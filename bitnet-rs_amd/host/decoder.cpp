@@ -2,6 +2,8 @@
 // bitnet_hip_* call (include/bitnet_hip.h) or plain HIP memory / stream / graph plumbing.
 #include "decoder.hpp"
 
+#include "blake3.hpp"
+
 #include <hip/hip_runtime_api.h>
 
 #include <dlfcn.h>
@@ -71,6 +73,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
         return;
     }
     if (const char *e = getenv("BITNET_HOST_LOGITS_WGS")) logits_wgs_ = atoi(e) > 0 ? atoi(e) : logits_wgs_;  // tuning knob
+    if (const char *e = getenv("BITNET_TRACE_DIR")) trace_dir_ = e;  // the reference's switch (crates/bitnet-trace/src/lib.rs:113-117)
     if (const char *e = getenv("BITNET_HOST_ACT")) act_mode_ = atoi(e) != 0 ? 1 : 0;  // 0: exact f32 activations between the kernels
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
@@ -356,46 +359,105 @@ int Decoder::position() {
     return p;
 }
 
+// Reads a device f32 vector back after the kernel that wrote it and leaves one trace record (reference format).
+struct Decoder::Tracer {
+    std::string dir;
+    int seq = 0;
+    void *stream = nullptr;
+    std::string err;
+    bool dump(const std::string &name, const char *stage, int layer, const float *dev, size_t n) {
+        std::vector<float> h(n);
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(h.data(), dev, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            err = "trace: read-back failed";
+            return false;
+        }
+        double ss = 0.0;
+        for (float v : h) ss += (double)v * (double)v;
+        const double rms = std::sqrt(ss / (double)n);
+        std::string file = name;
+        for (char &c : file)
+            if (c == '/' || c == '\\') c = '_';
+        FILE *f = fopen((dir + "/" + file + ".trace").c_str(), "w");
+        if (!f) {
+            err = "trace: cannot write into " + dir;
+            return false;
+        }
+        fprintf(f, "{\n  \"name\": \"%s\",\n  \"shape\": [\n    1,\n    %zu\n  ],\n  \"dtype\": \"F32\",\n  \"blake3\": \"%s\",\n  \"rms\": %.17g,\n"
+                   "  \"num_elements\": %zu,\n  \"seq\": %d,\n  \"layer\": %d,\n  \"stage\": \"%s\"\n}",
+                name.c_str(), n, Blake3::hex(h.data(), n * 4).c_str(), rms, n, seq, layer, stage);
+        fclose(f);
+        return true;
+    }
+};
+#define TRACE(name, stage, layer, ptr, n)                                   \
+    do {                                                                    \
+        if (tr && !tr->dump(name, stage, layer, ptr, n)) {                  \
+            err_ = tr->err;                                                 \
+            return BITNET_HIP_ERR_EXECUTION;                                \
+        }                                                                   \
+    } while (0)
+
 // One decode step = TransformerModel::forward (T:1557-1597) on one token + logits.
-int Decoder::step_launches(bool with_logits, int form) {
+int Decoder::step_launches(bool with_logits, int form, Tracer *tr) {
     void *s = stream_;
     const size_t H = c_.hidden;
+    const size_t tQD = (size_t)c_.n_heads * c_.head_dim, tKD = (size_t)c_.n_kv_heads * c_.head_dim;
+    const std::string tp = tr ? "t" + std::to_string(tr->seq) + "/" : "";
+    if (tr && form == 1) form = 0;  // the merging o-projection never materialises the attention output
     if (qact_path()) {
         // Every vector that travels between two GEMVs goes as a QAct written by its producer's epilogue (x: embedding /
         // down-projection, attention output: combine kernel or merging o-projection, x2: o-projection, h: gate|up).
         const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
         BCHK(bitnet_hip_embed_q_dev(embed_, history_, pos_, H, (size_t)c_.vocab, x_, layers_[0].attn_norm, qa_x_, st_x_, s));
+        TRACE(tp + "embeddings", "embeddings", -1, x_, H);
         for (size_t l = 0; l < layers_.size(); ++l) {
             Layer &L = layers_[l];
+            const std::string bp = tp + "blk" + std::to_string(l) + "/";
             BCHK(bitnet_hip_gemv_q_dev(L.qkv, qa_x_, st_x_, L.attn_norm, c_.eps, nullptr, 0, qkv_, nullptr, nullptr, nullptr, s));
+            TRACE(bp + "q_proj", "q_proj", (int)l, qkv_, tQD);
+            TRACE(bp + "k_proj", "k_proj", (int)l, qkv_ + tQD, tKD);
+            TRACE(bp + "v_proj", "v_proj", (int)l, qkv_ + tQD + tKD, tKD);
             if (form == 1) {
                 BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, s));
                 BCHK(bitnet_hip_gemv_attn_merge_q_dev(L.o, attn_scratch_, NH, NK, MP, pos_, x2_, x_, qa_x2_, L.ffn_norm, st_x2_, s));
             } else {
                 BCHK(bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, form == 2 ? 1 : 0,
-                                                       nullptr, qa_att_, s));
+                                                       tr ? att_ : nullptr, qa_att_, s));
+                TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
                 BCHK(bitnet_hip_gemv_q_dev(L.o, qa_att_, nullptr, nullptr, 0.f, x_, 0, x2_, qa_x2_, L.ffn_norm, st_x2_, s));
             }
-            BCHK(bitnet_hip_gemv_q_dev(L.gateup, qa_x2_, st_x2_, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, nullptr, qa_h_, nullptr, nullptr, s));
+            TRACE(bp + "attn_residual", "attn_residual", (int)l, x2_, H);
+            BCHK(bitnet_hip_gemv_q_dev(L.gateup, qa_x2_, st_x2_, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, tr ? h_ : nullptr, qa_h_, nullptr, nullptr, s));
+            TRACE(bp + "ffn_hidden", "ffn_hidden", (int)l, h_, (size_t)c_.ffn);
             const bool more = l + 1 < layers_.size();
             BCHK(bitnet_hip_gemv_q_dev(L.down, qa_h_, nullptr, nullptr, 0.f, x2_, 0, x_, more ? qa_x_ : nullptr, more ? layers_[l + 1].attn_norm : nullptr,
                                        more ? st_x_ : nullptr, s));
+            TRACE(bp + "ffn_out", "ffn_out", (int)l, x_, H);
         }
+        if (tr) TRACE("t" + std::to_string(tr->seq) + "_all_layers_out", "all_layers_out", -1, x_, H);
         if (with_logits) {
             BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_, (size_t)logits_wgs_, token_, pos_,
                                            history_, n_forced_, s));
+            TRACE(tp + "logits", "logits", -1, logits_, (size_t)c_.vocab);
         } else {
             BCHK(bitnet_hip_advance_pos_dev(pos_, s));
         }
         return 0;
     }
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, 1, H, (size_t)c_.vocab, x_, s));
-    for (auto &L : layers_) {
+    TRACE(tp + "embeddings", "embeddings", -1, x_, H);
+    for (size_t l = 0; l < layers_.size(); ++l) {
+        Layer &L = layers_[l];
+        const std::string bp = tp + "blk" + std::to_string(l) + "/";
         // attention_norm -> q,k,v (T:1015, T:288-290), fused into one launch
         BCHK(bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, s));
+        TRACE(bp + "q_proj", "q_proj", (int)l, qkv_, tQD);
+        TRACE(bp + "k_proj", "k_proj", (int)l, qkv_ + tQD, tKD);
+        TRACE(bp + "v_proj", "v_proj", (int)l, qkv_ + tQD + tKD, tKD);
         if (form == 2) {
             BCHK(bitnet_hip_attention_decode_wide_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
                                                       (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
             BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
         } else if (form == 1) {
             // short contexts: one attention launch; the o-projection merges the chunk records itself
@@ -405,21 +467,56 @@ int Decoder::step_launches(bool with_logits, int form) {
         } else {
             BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
                                                  (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
             // o_proj + residual (T:542, T:1073)
             BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
         }
+        TRACE(bp + "attn_residual", "attn_residual", (int)l, x2_, H);
         // post_attention_layernorm -> gate, up -> silu(gate)*up (T:1104, T:756-781)
         BCHK(bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, s));
+        TRACE(bp + "ffn_hidden", "ffn_hidden", (int)l, h_, (size_t)c_.ffn);
         // down_proj + residual (T:789, T:1125)
         BCHK(bitnet_hip_gemv_fused_dev(L.down, h_, x_, 1, nullptr, 0.f, x2_, 0, s));
+        TRACE(bp + "ffn_out", "ffn_out", (int)l, x_, H);
     }
+    if (tr) TRACE("t" + std::to_string(tr->seq) + "_all_layers_out", "all_layers_out", -1, x_, H);
     if (with_logits) {
         // final norm + tied logits + greedy token (T:1589, T:1599-1630, sampling.rs:189-202)
         BCHK(bitnet_hip_logits_f16_dev(embed_, x_, final_norm_, c_.eps, H, (size_t)c_.vocab, logits_, scratch_,
                                        (size_t)logits_wgs_, token_, pos_, history_, n_forced_, s));
+        TRACE(tp + "logits", "logits", -1, logits_, (size_t)c_.vocab);
     } else {
         BCHK(bitnet_hip_advance_pos_dev(pos_, s));
     }
+    return 0;
+}
+
+int Decoder::trace_step(const char *dir, bool with_logits) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (!dir || !*dir) {
+        err_ = "trace_step: no directory";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    const int p = position();
+    if (p < 0) return BITNET_HIP_ERR_GPU;
+    if (p + 1 > c_.max_pos - 1) {
+        err_ = "KV cache overflow";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (!with_logits && p + 1 > host_forced_) {
+        err_ = "trace_step(with_logits = false) past the fed tokens";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    Tracer tr;
+    tr.dir = dir;
+    tr.seq = p;  // token position of this step (the reference counts 0 = first position)
+    tr.stream = stream_;
+    const int rc = step_launches(with_logits, form_at(p), &tr);
+    if (rc) return rc;
+    HCHK(hipStreamSynchronize((hipStream_t)stream_));
     return 0;
 }
 
@@ -522,6 +619,14 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
         // a step without logits samples nothing: the NEXT position's token must already be in the history
         err_ = "run(with_logits = false) past the fed tokens: nothing would choose the next token";
         return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (!trace_dir_.empty()) {  // BITNET_TRACE_DIR: every step eagerly, with read-backs (slow by design)
+        for (int i = 0; i < n; ++i) {
+            const int rc = trace_step(trace_dir_.c_str(), with_logits);
+            if (rc) return rc;
+        }
+        if (elapsed_ms) *elapsed_ms = 0.f;
+        return 0;
     }
     hipStream_t s = (hipStream_t)stream_;
     if (use_graph) {
@@ -783,10 +888,6 @@ int Decoder::last_hidden(float *out) {
     HCHK(hipMemcpy(out, x_, (size_t)c_.hidden * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int Decoder::layer_trace(float *) {
-    err_ = "layer trace is not kept";
-    return BITNET_HIP_ERR_UNSUPPORTED;
-}
 
 // kind: 0 q|k|v, 1 attention, 2 o_proj, 3 gate|up, 4 down, 5 logits+argmax
 int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *bytes_per_launch) {
@@ -975,6 +1076,13 @@ int bitnet_host_position(void *d) { return static_cast<Decoder *>(d)->position()
 int bitnet_host_history(void *d, int32_t *out, int n) { return static_cast<Decoder *>(d)->history(out, n); }
 int bitnet_host_last_logits(void *d, float *out) { return static_cast<Decoder *>(d)->last_logits(out); }
 int bitnet_host_last_hidden(void *d, float *out) { return static_cast<Decoder *>(d)->last_hidden(out); }
+int bitnet_host_blake3_hex(const void *data, size_t len, char *out65) {
+    if (!out65 || (!data && len)) return -1;
+    const std::string h = bitnet_host::Blake3::hex(data, len);
+    memcpy(out65, h.c_str(), 65);
+    return 0;
+}
+int bitnet_host_trace_step(void *d, const char *dir, int with_logits) { return static_cast<Decoder *>(d)->trace_step(dir, with_logits != 0); }
 int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch) {
     return static_cast<Decoder *>(d)->probe_gateup(reps, us_per_launch, bytes_per_launch);
 }

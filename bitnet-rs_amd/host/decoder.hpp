@@ -118,7 +118,12 @@ class Decoder {
     int history(int32_t *out, int n);                // first n tokens of the sequence
     int last_logits(float *out);                     // [vocab], of the last step run with logits
     int last_hidden(float *out);                     // residual stream after the last block (pre final norm)
-    int layer_trace(float *out);                     // eager debug: not kept (returns error)
+    // Activation trace of ONE decode step in the reference's format (crates/bitnet-trace/src/lib.rs:46-168: one JSON file per
+    // tensor -- name, shape, dtype, blake3 of the raw f32 bytes, rms, num_elements, seq, layer, stage -- in `dir`): the step
+    // runs eagerly, every intermediate is materialised as f32 and read back after its kernel.  Stages: embeddings; per
+    // block q_proj, k_proj, v_proj, attn_out, attn_residual, ffn_hidden, ffn_out; all_layers_out; logits.  Off the hot path.
+    // run() does this for every step when BITNET_TRACE_DIR is set (the reference's switch).
+    int trace_step(const char *dir, bool with_logits);
     // Dominant-kernel probe for bench.py: every layer's fused gate/up GEMV back to back in
     // one graph, `reps` replays; returns the mean time per launch and the algorithmic
     // bytes one launch reads.
@@ -132,7 +137,8 @@ class Decoder {
     int fail(const char *what);
     // attention form of a step: 0 = two kernels, 64-position chunks; 1 = one kernel + merging o-projection (short
     // contexts); 2 = two kernels, 128-position chunks (more chunks than CUs)
-    int step_launches(bool with_logits, int form);
+    struct Tracer;
+    int step_launches(bool with_logits, int form, Tracer *tr = nullptr);
     int step_launches_reference(bool with_logits);
     int ensure_graph(bool with_logits, int form);
     int form_at(int pos) const;
@@ -158,6 +164,7 @@ class Decoder {
     void *qa_x_ = nullptr, *qa_x2_ = nullptr, *qa_att_ = nullptr, *qa_h_ = nullptr;  // QAct records of x, x2, attention output, silu(gate)*up
     double *st_x_ = nullptr, *st_x2_ = nullptr;                                       // LayerNorm statistics pairs of x, x2
     int act_mode_ = 1;
+    std::string trace_dir_;  // BITNET_TRACE_DIR at construction
     float *ref_n_ = nullptr, *ref_gu_ = nullptr, *ref_t_ = nullptr;  // unfused reference step: normalised row, gate|up tiles, projection out
     void *scratch_ = nullptr;
     float *attn_scratch_ = nullptr;
@@ -215,6 +222,8 @@ int bitnet_host_position(void *d);
 int bitnet_host_history(void *d, int32_t *out, int n);
 int bitnet_host_last_logits(void *d, float *out);
 int bitnet_host_last_hidden(void *d, float *out);
+int bitnet_host_trace_step(void *d, const char *dir, int with_logits);
+int bitnet_host_blake3_hex(const void *data, size_t len, char *out65);  // the trace records' hash (host/blake3.hpp), 64 hex digits + NUL
 int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch);
 int bitnet_host_probe_kernel(void *d, int kind, int reps, float *us_per_launch, double *bytes_per_launch);
 uint64_t bitnet_host_weight_bytes(void *d);
