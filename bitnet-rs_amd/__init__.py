@@ -241,6 +241,14 @@ class HipLib:
         )
         return c
 
+    def quantized_matmul_i2s(self, x, packed, scales, block_size: int, m: int, n: int, k: int) -> np.ndarray:
+        xa, pa, sa = _np(x, np.float32), _np(packed, np.uint8), _np(scales, np.float32)
+        out = np.zeros(m * n, np.float32)
+        self.c.bitnet_hip_quantized_matmul_i2s.argtypes = [_f32p, _sz, _u8p, _sz, _f32p, _sz, _sz, _f32p, _sz, _sz, _sz, _sz]
+        self._check(self.c.bitnet_hip_quantized_matmul_i2s(xa.ctypes.data_as(_f32p), xa.size, pa.ctypes.data_as(_u8p), pa.size, sa.ctypes.data_as(_f32p), sa.size,
+                                                           block_size, out.ctypes.data_as(_f32p), out.size, m, n, k))
+        return out
+
     def quantize(self, x, qtype=QTYPE_I2S, out_len=None, scales_len=None, out_init=None):
         xa = _np(x, np.float32)
         out = np.zeros(xa.size // 4 if out_len is None else out_len, np.uint8) if out_init is None else _np(out_init, np.uint8).copy()

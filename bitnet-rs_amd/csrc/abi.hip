@@ -1168,8 +1168,48 @@ int bitnet_hip_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_
         return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in matmul_i2s");
     BH_HIP_TRY(hipMemcpy(ad.p, a, a_len, hipMemcpyHostToDevice));
     BH_HIP_TRY(hipMemcpy(bd.p, b, b_len, hipMemcpyHostToDevice));
-    BH_HIP_TRY(launch_matmul_i2s_u8(ad.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
+    // integer tiles (v_dot4_u32_u8) unless the caller pinned the reference-order kernel or the shape is odd
+    if (g_kernel.load(std::memory_order_relaxed) != BITNET_HIP_KERNEL_EXACT && matmul_i2s_tiled_ok(m, n, k))
+        BH_HIP_TRY(launch_matmul_i2s_tiled(ad.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
+    else
+        BH_HIP_TRY(launch_matmul_i2s_u8(ad.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
     BH_HIP_TRY(hipMemcpy(c, cd.p, c_len * 4, hipMemcpyDeviceToHost));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+/* QuantizedLinear::quantized_matmul_i2s (crates/bitnet-inference/src/layers/quantized_linear.rs:704-802), all on the device:
+ * input -> i8 by clamp(x, -2, 1).round() (:1762-1773); packed 2-bit weights -> raw codes 0..3 as the [k, n] u8 operand
+ * (:769-776); matmul_i2s; per-output scale (:779-802). */
+int bitnet_hip_quantized_matmul_i2s(const float *input, size_t in_len, const uint8_t *weights_packed, size_t w_len, const float *scales,
+                                    size_t scales_len, size_t block_size, float *output, size_t out_len, size_t m, size_t n, size_t k) {
+    BH_GUARD_BEGIN
+    if (!input || !weights_packed || !output || (!scales && scales_len))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to quantized_matmul_i2s");
+    BH_CHECK_DIMS(m, n, k);
+    if (block_size == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "block_size must be > 0");
+    if (in_len != m * k) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix A dimension mismatch: expected %zu, got %zu", m * k, in_len);
+    if (w_len < div_ceil(k * n, 4))  // unpack_2bit_values would come up short and matmul_i2s refuse b (K/cpu/fallback.rs:54-58)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix B dimension mismatch: expected %zu, got %zu", k * n, w_len * 4);
+    if (out_len != m * n) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Matrix C dimension mismatch: expected %zu, got %zu", m * n, out_len);
+    if (m * n == 0) return BITNET_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf xd, qd, wd, bd, cd, sd;
+    if (xd.alloc(in_len * 4) != hipSuccess || qd.alloc(in_len + 16) != hipSuccess || wd.alloc(w_len) != hipSuccess || bd.alloc(k * n + 16) != hipSuccess ||
+        cd.alloc(out_len * 4) != hipSuccess || sd.alloc(scales_len * 4) != hipSuccess)
+        return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in quantized_matmul_i2s");
+    BH_HIP_TRY(hipMemcpy(xd.p, input, in_len * 4, hipMemcpyHostToDevice));
+    BH_HIP_TRY(hipMemcpy(wd.p, weights_packed, w_len, hipMemcpyHostToDevice));
+    if (scales_len) BH_HIP_TRY(hipMemcpy(sd.p, scales, scales_len * 4, hipMemcpyHostToDevice));
+    BH_HIP_TRY(launch_quant_input_i2s(xd.as<float>(), qd.as<int8_t>(), in_len, nullptr));
+    BH_HIP_TRY(launch_unpack_codes_u8(wd.as<uint8_t>(), bd.as<uint8_t>(), k * n, nullptr));
+    if (g_kernel.load(std::memory_order_relaxed) != BITNET_HIP_KERNEL_EXACT && matmul_i2s_tiled_ok(m, n, k))
+        BH_HIP_TRY(launch_matmul_i2s_tiled(qd.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
+    else
+        BH_HIP_TRY(launch_matmul_i2s_u8(qd.as<int8_t>(), bd.as<uint8_t>(), cd.as<float>(), m, n, k, nullptr));
+    BH_HIP_TRY(launch_apply_scales(cd.as<float>(), m, n, sd.as<float>(), scales_len, k, block_size, nullptr));
+    BH_HIP_TRY(hipMemcpy(output, cd.p, out_len * 4, hipMemcpyDeviceToHost));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
@@ -1195,7 +1235,10 @@ int bitnet_hip_quantize(const float *input, size_t input_len, uint8_t *output, s
         return set_error(BITNET_HIP_ERR_GPU, "hipMalloc failed in quantize");
     BH_HIP_TRY(hipMemcpy(id.p, input, input_len * 4, hipMemcpyHostToDevice));
     BH_HIP_TRY(hipMemcpy(od.p, output, output_len, hipMemcpyHostToDevice));  // OR-pack semantics
-    BH_HIP_TRY(launch_quantize_i2s(id.as<float>(), input_len, od.as<uint8_t>(), output_len, sd.as<float>(), nullptr));
+    if (input_len % 32 == 0 && g_kernel.load(std::memory_order_relaxed) != BITNET_HIP_KERNEL_EXACT)
+        BH_HIP_TRY(launch_quantize_i2s_fast(id.as<float>(), input_len, od.as<uint8_t>(), output_len, sd.as<float>(), nullptr));  // same values, coalesced
+    else
+        BH_HIP_TRY(launch_quantize_i2s(id.as<float>(), input_len, od.as<uint8_t>(), output_len, sd.as<float>(), nullptr));
     BH_HIP_TRY(hipMemcpy(output, od.p, output_len, hipMemcpyDeviceToHost));
     BH_HIP_TRY(hipMemcpy(scales, sd.p, num_blocks * 4, hipMemcpyDeviceToHost));
     return BITNET_HIP_OK;

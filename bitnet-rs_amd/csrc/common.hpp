@@ -147,6 +147,14 @@ hipError_t launch_matmul_i2s_u8(const int8_t *a, const uint8_t *b, float *c, siz
                                 size_t k, hipStream_t stream);
 hipError_t launch_quantize_i2s(const float *in, size_t n, uint8_t *out, size_t out_len, float *scales,
                                hipStream_t stream);
+// kernels_provider.hip: the trait ops at speed + the pieces of QuantizedLinear::quantized_matmul_i2s
+bool matmul_i2s_tiled_ok(size_t m, size_t n, size_t k);
+hipError_t launch_matmul_i2s_tiled(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n, size_t k, hipStream_t stream);
+hipError_t launch_quantize_i2s_fast(const float *in, size_t n, uint8_t *out, size_t out_len, float *scales, hipStream_t stream);
+hipError_t launch_quant_input_i2s(const float *x, int8_t *q, size_t n, hipStream_t stream);
+hipError_t launch_unpack_codes_u8(const uint8_t *packed, uint8_t *out, size_t numel, hipStream_t stream);
+hipError_t launch_apply_scales(float *out, size_t m, size_t n, const float *scales, size_t n_scales, size_t in_features, size_t block_size,
+                               hipStream_t stream);
 hipError_t launch_dequant_i2s(const uint8_t *bytes, size_t rows, size_t cols, size_t block, int inv,
                               float k, int transposed, float *out, hipStream_t stream);
 

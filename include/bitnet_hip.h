@@ -123,6 +123,16 @@ int bitnet_hip_qk256_gemv(const uint8_t *weights, size_t w_len, const float *sca
 int bitnet_hip_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_t b_len, float *c,
                           size_t c_len, size_t m, size_t n, size_t k);
 
+/* QuantizedLinear::quantized_matmul_i2s(input, provider)  crates/bitnet-inference/src/layers/quantized_linear.rs:704-802 --
+ * the composite the alternative layer runs above the trait: input [m, k] f32 -> i8 by clamp(x, -2, 1).round()
+ * (quantize_input_i2s :1762-1773); weights_packed = the layer's 2-bit data, unpacked LSB-first to RAW codes 0..3 and handed
+ * to matmul_i2s as its u8 [k, n] row-major operand exactly as the reference does (:769-776, :722-731); then every output
+ * column times scales[col] (one scale per output feature) or scales[min(col * k / block_size, len - 1)] (:779-802,
+ * input_scale = 1).  Lossy by construction in the reference too; restated quirk for quirk (oracle: bo_quantized_matmul_i2s). */
+int bitnet_hip_quantized_matmul_i2s(const float *input, size_t in_len, const uint8_t *weights_packed, size_t w_len,
+                                    const float *scales, size_t scales_len, size_t block_size, float *output,
+                                    size_t out_len, size_t m, size_t n, size_t k);
+
 /* KernelProvider::quantize(input, output, scales, qtype)  K/lib.rs:53-58;
  * I2S arithmetic of K/cpu/fallback.rs:102-159 (block 32, scale = absmax/1.5,
  * >0.5 -> 1, <-0.5 -> 3, else 0, OR-packed LSB-first into `output`, which the

@@ -478,6 +478,47 @@ int bo_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
     return 0;
 }
 
+/* QuantizedLinear::quantized_matmul_i2s, crates/bitnet-inference/src/layers/quantized_linear.rs:704-744 with its helpers:
+ *   quantize_input_i2s      :1762-1773   x.clamp(-2.0, 1.0).round() as i8  (f32::round: half away from zero; NaN as i8 = 0)
+ *   prepare_quantized_weights_i2s :769-776 + unpack_2bit_values :1738-1759   (code - 2) + 2 = the RAW code 0..3, LSB first,
+ *                                                     `numel` = k * n values, handed to matmul_i2s as its [k, n] operand
+ *   provider.matmul_i2s     :722-731      FallbackKernel, K/cpu/fallback.rs:39-83 (above)
+ *   apply_quantization_scales :779-802    scale index = col if scales.len() == out_features, else
+ *                                         min((col * in_features) / block_size, scales.len() - 1); input_scale = 1.0;
+ *                                         scales.get(idx).unwrap_or(1.0) */
+int bo_quantized_matmul_i2s(const float *input, size_t in_len, const uint8_t *packed, size_t packed_len, const float *scales,
+                            size_t n_scales, size_t block_size, float *out, size_t out_len, size_t m, size_t n, size_t k,
+                            char *err) {
+    if (in_len != m * k) return fail(err, "Matrix A dimension mismatch: expected %zu, got %zu", m * k, in_len);
+    size_t numel = k * n;
+    int8_t *a = (int8_t *)malloc(in_len ? in_len : 1);
+    uint8_t *b = (uint8_t *)malloc(numel ? numel : 1);
+    size_t nb = 0;
+    for (size_t i = 0; i < in_len; ++i) {
+        float x = input[i];
+        float c = x < -2.0f ? -2.0f : (x > 1.0f ? 1.0f : x); /* f32::clamp: NaN stays NaN */
+        a[i] = (c != c) ? (int8_t)0 : (int8_t)roundf(c);
+    }
+    for (size_t i = 0; i < packed_len && nb < numel; ++i)
+        for (int shift = 0; shift < 8 && nb < numel; shift += 2) b[nb++] = (uint8_t)((((packed[i] >> shift) & 3) - 2) + 2);
+    int rc = bo_matmul_i2s(a, in_len, b, nb, out, out_len, m, n, k, err); /* a short weight buffer fails B's length check */
+    free(a);
+    free(b);
+    if (rc) return rc;
+    for (size_t row = 0; row < m; ++row)
+        for (size_t col = 0; col < n; ++col) {
+            size_t idx = col;
+            if (n_scales != n) {
+                size_t weight_idx = col * k;
+                idx = weight_idx / block_size;
+                if (n_scales == 0 || idx > n_scales - 1) idx = n_scales ? n_scales - 1 : 0;
+            }
+            float scale = idx < n_scales ? scales[idx] : 1.0f;
+            out[row * n + col] *= 1.0f * scale;
+        }
+    return 0;
+}
+
 /* K/cpu/fallback.rs:102-159.  NB: OR-packs into `output` without clearing it
  * first (:153) -- callers pass a zeroed buffer; restated as-is. */
 int bo_quantize_i2s(const float *input, size_t input_len, uint8_t *output, size_t output_len,

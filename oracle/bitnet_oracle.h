@@ -97,6 +97,9 @@ int bo_dequantize_and_matmul(const float *act, size_t act_len, const uint8_t *w,
 /* ---- KernelProvider (FallbackKernel) : K/cpu/fallback.rs -------------- */
 
 /* K/cpu/fallback.rs:39-83   C = A_i8 . B_u8, B unpacked row-major [k,n] */
+int bo_quantized_matmul_i2s(const float *input, size_t in_len, const uint8_t *packed, size_t packed_len, const float *scales,
+                            size_t n_scales, size_t block_size, float *out, size_t out_len, size_t m, size_t n, size_t k,
+                            char *err);
 int bo_matmul_i2s(const int8_t *a, size_t a_len, const uint8_t *b, size_t b_len, float *c,
                   size_t c_len, size_t m, size_t n, size_t k, char *err);
 /* K/cpu/fallback.rs:102-159  block 32, scale = absmax/1.5, OR-packs into output */

@@ -222,6 +222,20 @@ def matmul_i2s(a, b, m, n, k, c_len=None) -> np.ndarray:
     return c
 
 
+def quantized_matmul_i2s(x, packed, scales, block_size, m, n, k) -> np.ndarray:
+    """QuantizedLinear::quantized_matmul_i2s (quantized_linear.rs:704-802)."""
+    xa, xp = _f32(x)
+    pa, pp = _u8(packed)
+    sa, sp = _f32(scales)
+    out = np.zeros(m * n, np.float32)
+    err = C.create_string_buffer(ERRLEN)
+    L = lib()
+    L.bo_quantized_matmul_i2s.argtypes = [_f32p, _sz, _u8p, _sz, _f32p, _sz, _sz, _f32p, _sz, _sz, _sz, _sz, C.c_char_p]
+    L.bo_quantized_matmul_i2s.restype = C.c_int
+    _check(L.bo_quantized_matmul_i2s(xp, xa.size, pp, pa.size, sp, sa.size, block_size, out.ctypes.data_as(_f32p), out.size, m, n, k, err), err)
+    return out
+
+
 def quantize_i2s(x, out_len=None, scales_len=None):
     xa, xp = _f32(x)
     out = np.zeros(xa.size // 4 if out_len is None else out_len, np.uint8)

@@ -248,6 +248,38 @@ def test_device_handle_api_and_batched_rows(hip, pkg, oracle):
 # ----------------------------------------------------------- provider trait
 
 
+def test_quantized_matmul_i2s_composite(hip, pkg, oracle):
+    """The a8 composite (quantize_input_i2s -> matmul_i2s on raw codes -> block scale) against its oracle restatement, bit
+    for bit (every intermediate is a small integer), on both device kernels; shapes from the model's projections."""
+    rng = np.random.default_rng(12)
+    for m, n, k, bs, per_feature in [(1, 8, 16, 32, True), (3, 640, 2560, 32, False), (2, 2560, 6912, 32, True), (5, 12, 20, 4, False), (1, 6, 10, 32, False)]:
+        x = rng.normal(0, 1.2, m * k).astype(np.float32)
+        x[::17] = np.round(x[::17]) + 0.5  # ties: f32::round goes away from zero
+        packed = rng.integers(0, 256, -(-k * n // 4), dtype=np.uint8)
+        scales = rng.uniform(0.1, 2.0, n if per_feature else max(1, k * n // bs // 3)).astype(np.float32)
+        want = oracle.quantized_matmul_i2s(x, packed, scales, bs, m, n, k)
+        for kern in (pkg.KERNEL_AUTO, pkg.KERNEL_EXACT):
+            hip.set_kernel(kern)
+            assert np.array_equal(hip.quantized_matmul_i2s(x, packed, scales, bs, m, n, k), want), (m, n, k, kern)
+    hip.set_kernel(pkg.KERNEL_AUTO)
+    with pytest.raises(pkg.BitNetHipError, match="Matrix B dimension mismatch"):
+        hip.quantized_matmul_i2s(np.zeros(4, np.float32), np.zeros(1, np.uint8), np.ones(2, np.float32), 32, 1, 2, 4)
+
+
+def test_matmul_i2s_tiled_full_byte_ranges(hip, pkg, oracle):
+    """The integer-tile kernel on the trait's FULL operand ranges (a in [-128, 127], b in [0, 255]) at k where every f32
+    partial sum of the reference is still exact (128 * 255 * k < 2^24): identical to the scalar oracle."""
+    rng = np.random.default_rng(13)
+    for m, n, k in [(1, 4, 4), (9, 64, 512), (2, 4096, 256), (17, 12, 64)]:
+        a = rng.integers(-128, 128, m * k).astype(np.int8)
+        b = rng.integers(0, 256, k * n).astype(np.uint8)
+        assert np.array_equal(hip.matmul_i2s(a, b, m, n, k), oracle.matmul_i2s(a, b, m, n, k)), (m, n, k)
+    # I2_S value ranges at the model's shapes (the call the composite makes)
+    a = rng.integers(-2, 2, 4 * 6912).astype(np.int8)
+    b = rng.integers(0, 4, 6912 * 2560).astype(np.uint8)
+    assert np.array_equal(hip.matmul_i2s(a, b, 4, 2560, 6912), oracle.matmul_i2s(a, b, 4, 2560, 6912))
+
+
 def test_matmul_i2s_provider_exact(hip, oracle):
     """K/cpu/fallback.rs:306-318 + random: integer-valued, must be bit-exact."""
     assert hip.matmul_i2s([1, 2, 3, 4], [1, 0, 0, 1], 2, 2, 2).tolist() == [1.0, 2.0, 3.0, 4.0]

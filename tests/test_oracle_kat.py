@@ -592,3 +592,20 @@ def test_rotary_embedding_behaviour(oracle):
     x = np.ones((1, 2, 1, 32), np.float32)
     assert np.abs(oracle.rope_apply(x, 0) - oracle.rope_apply(x, 5)).max() > 1e-7
     assert np.array_equal(oracle.rope_apply(x, 3), oracle.rope_apply(x, 3))
+
+
+def test_quantized_matmul_i2s_composite_worked_example(oracle):
+    """QuantizedLinear::quantized_matmul_i2s (quantized_linear.rs:704-802) by hand: m=1, k=4, n=2.
+    input [0.4, 1.7, -3.0, -0.5] -> clamp(-2,1).round() = [0, 1, -2, -1] (-0.5 rounds away from zero);
+    packed 0b11100100, 0b00011011 -> raw codes [0,1,2,3, 3,2,1,0] = B[4,2] rows (0,1),(2,3),(3,2),(1,0);
+    C = [0*0 + 1*2 - 2*3 - 1*1, 0*1 + 1*3 - 2*2 - 1*0] = [-5, -1]; one scale per output feature [0.5, 2] -> [-2.5, -2]."""
+    x = np.array([0.4, 1.7, -3.0, -0.5], np.float32)
+    packed = np.array([0b11100100, 0b00011011], np.uint8)
+    assert oracle.quantized_matmul_i2s(x, packed, np.array([0.5, 2.0], np.float32), 32, 1, 2, 4).tolist() == [-2.5, -2.0]
+    # block-indexed scales (scales.len() != out_features): idx = min(col * k / block_size, len - 1) -> col 0 -> 0, col 1 -> min(4 / 2, 2) = 2
+    got = oracle.quantized_matmul_i2s(x, packed, np.array([10.0, 100.0, 1000.0], np.float32), 2, 1, 2, 4)
+    assert got.tolist() == [-50.0, -1000.0]
+    # NaN input quantises to 0; a weight buffer that is too short fails matmul_i2s's B check
+    assert oracle.quantized_matmul_i2s(np.array([np.nan, 1, 1, 1], np.float32), packed, np.array([1.0, 1.0], np.float32), 32, 1, 2, 4).tolist() == [2 + 3 + 1, 3 + 2 + 0]
+    with pytest.raises(oracle.OracleError, match="Matrix B dimension mismatch"):
+        oracle.quantized_matmul_i2s(x, packed[:1], np.array([1.0, 1.0], np.float32), 32, 1, 2, 4)

@@ -30,3 +30,7 @@ for WL in c2 c3 c4; do
     python3 tools/profile_summary.py "$D" "$TAG" "$WL" || exit 1
     echo "== $WL done"
 done
+# the provider-trait ops (a9 / a10 / a12) and the a8 composite: device times per kernel
+mkdir -p "$OUT/provider"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/provider/trace" -- python3 tools/perf_provider.py > "$OUT/provider/perf_provider.log" 2>&1 || { tail -5 "$OUT/provider/perf_provider.log"; exit 1; }
+python3 tools/profile_summary.py "$OUT/provider" "$TAG" provider || exit 1

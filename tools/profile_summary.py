@@ -87,6 +87,8 @@ def main():
 
     shutil.copy(os.path.join(out_dir, "summary.md"), os.path.join(prof, f"{tag}_{wl}_summary.md"))
     shutil.copy(os.path.join(out_dir, "summary.json"), os.path.join(prof, f"{tag}_{wl}_summary.json"))
+    if os.path.exists(os.path.join(out_dir, "perf_provider.log")):
+        shutil.copy(os.path.join(out_dir, "perf_provider.log"), os.path.join(prof, f"{tag}_{wl}_host_wall.txt"))
     if os.path.exists(os.path.join(out_dir, "bench.json")):
         shutil.copy(os.path.join(out_dir, "bench.json"), os.path.join(prof, f"{tag}_{wl}_bench.json"))
     with open(os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
