@@ -396,9 +396,10 @@ class HipLib:
                                                  _optr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
     def attention_decode_q_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, qact_out,
-                               wide: bool = False, stream: int = 0) -> None:
+                               wide: bool = False, kv_f16: bool = False, stream: int = 0) -> None:
+        flags = (1 if wide else 0) | (2 if kv_f16 else 0)
         self._check(self.c.bitnet_hip_attention_decode_q_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
-                                                             head_dim, max_pos, _ptr(pos), _ptr(scratch), int(wide), _optr(out), _optr(qact_out), _vp(stream)))
+                                                             head_dim, max_pos, _ptr(pos), _ptr(scratch), flags, _optr(out), _optr(qact_out), _vp(stream)))
 
     def gemv_attn_merge_q_dev(self, h: int, scratch, n_heads, n_kv, max_pos, pos, y, qact_out, residual=None, gamma_out=None, stats_out=None,
                               stream: int = 0) -> None:
@@ -686,6 +687,11 @@ class HostDecoder:
         ms = C.c_float(0)
         self._check(self.c.bitnet_host_run(self.h, n, int(with_logits), int(use_graph), C.byref(ms)))
         return ms.value
+
+    def set_kv_f16(self, on: bool) -> None:
+        """Opt-in f16 KV cache (fresh sequence only)."""
+        self.c.bitnet_host_set_kv_f16.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.c.bitnet_host_set_kv_f16(self.h, int(on)))
 
     def set_act_mode(self, mode: int) -> None:
         """1 (default): activations quantised once by their producer (QAct); 0: exact f32 activations."""

@@ -870,19 +870,20 @@ int bitnet_hip_gemv_q_dev(bitnet_hip_weights_t h, const void *qact_in, const dou
     BH_GUARD_END
 }
 
-int bitnet_hip_attention_decode_q_dev(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache, float *vcache,
+int bitnet_hip_attention_decode_q_dev(const float *qkv, const float *rope_sin, const float *rope_cos, void *kcache, void *vcache,
                                       size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos, const int32_t *pos_dev,
-                                      float *scratch, int wide, float *out, void *qact_out, void *stream) {
+                                      float *scratch, int flags, float *out, void *qact_out, void *stream) {
+    const int wide = (flags & BITNET_HIP_ATTN_WIDE) != 0, kv16 = (flags & BITNET_HIP_ATTN_KV_F16) != 0, partial = (flags & BITNET_HIP_ATTN_PARTIAL) != 0;
     BH_GUARD_BEGIN
-    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch || (!out && !qact_out))
+    if (!qkv || !rope_sin || !rope_cos || !kcache || !vcache || !pos_dev || !scratch || (!out && !qact_out && !partial))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to attention_decode_q_dev");
     if (n_kv_heads == 0 || n_heads % n_kv_heads != 0)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "num_heads %zu must be divisible by num_key_value_heads %zu", n_heads, n_kv_heads);
     if (head_dim != 128 || n_heads / n_kv_heads > 4)
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "attention_decode: head_dim %zu / group %zu unsupported (head_dim 128, group <= 4)",
                          head_dim, n_heads / n_kv_heads);
-    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, pos_dev,
-                                  scratch, out, (hipStream_t)stream, true, wide ? 2 : 1, qact_out));
+    BH_HIP_TRY(launch_attn_decode(qkv, rope_sin, rope_cos, static_cast<float *>(kcache), static_cast<float *>(vcache), (int)n_heads, (int)n_kv_heads,
+                                  (int)head_dim, (int)max_pos, pos_dev, scratch, out, (hipStream_t)stream, !partial, wide ? 2 : 1, qact_out, kv16));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
@@ -945,9 +946,26 @@ int bitnet_hip_attention_prefill_sharded_dev(const float *q, size_t ld_q, const 
     BH_GUARD_END
 }
 
+int bitnet_hip_attention_prefill_kv16_dev(const float *qkv, const float *rope_sin, const float *rope_cos, void *kcache_f16, void *vcache_f16,
+                                          size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos, size_t seq_len, void *workspace,
+                                          size_t workspace_bytes, float *out, void *stream) {
+    BH_GUARD_BEGIN
+    int rc = check_prefill_args(qkv, qkv, rope_sin, rope_cos, kcache_f16, vcache_f16, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, seq_len);
+    if (rc) return rc;
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len, (int)seq_len);
+    if (workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
+    const int ld = (int)((n_heads + 2 * n_kv_heads) * head_dim);
+    BH_HIP_TRY(launch_attn_prefill(qkv, ld, nullptr, (int)seq_len, qkv + n_heads * head_dim, ld, (int)seq_len, rope_sin, rope_cos, static_cast<float *>(kcache_f16),
+                                   static_cast<float *>(vcache_f16), (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes, out,
+                                   (hipStream_t)stream, 0, 0, 1));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const int32_t *q_block_pos, size_t n_q, const void *kv_gathered,
                                               size_t n_ctx, size_t world, int kv_is_f16, const float *rope_sin, const float *rope_cos,
-                                              float *kcache, float *vcache, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
+                                              void *kcache, void *vcache, int cache_f16, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                               void *workspace, size_t workspace_bytes, float *out, void *stream) {
     BH_GUARD_BEGIN
     int rc = check_prefill_args(q, kv_gathered, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, n_ctx);
@@ -960,8 +978,8 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const
     if (workspace_bytes < need)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
     BH_HIP_TRY(launch_attn_prefill(q, (int)ld_q, q_block_pos, (int)n_q, static_cast<const float *>(kv_gathered), (int)(2 * n_kv_heads * head_dim), (int)n_ctx,
-                                   rope_sin, rope_cos, kcache, vcache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes,
-                                   out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0));
+                                   rope_sin, rope_cos, static_cast<float *>(kcache), static_cast<float *>(vcache), (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                   (int)max_pos, workspace, workspace_bytes, out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0, cache_f16 ? 1 : 0));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }

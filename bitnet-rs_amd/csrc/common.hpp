@@ -169,7 +169,8 @@ hipError_t launch_norm_rows(const float *x, const float *gamma, float *out, int 
                             bool rms, hipStream_t stream);
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine = true, int halves = 1, void *qout = nullptr);
+                              float *scratch, float *out, hipStream_t stream, bool combine = true, int halves = 1, void *qout = nullptr,
+                              int kv_f16 = 0);
 // decode attention chunk record (one per KV head and 64- or 128-position chunk) in the scratch buffer:
 // (m, l) per head of the query group [4][2], then the un-normalised P.V partial [4][128]
 constexpr int kAttnRecFloats = 8 + 4 * 128;
@@ -180,7 +181,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
                                int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream,
-                               int zz_world = 0, int kv_f16 = 0);
+                               int zz_world = 0, int kv_f16 = 0, int cache_f16 = 0);
 hipError_t launch_pack_cols(const float *src, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst, int f16, hipStream_t stream);
 hipError_t launch_stream_read(const void *buf, size_t bytes, unsigned *sink, hipStream_t stream);
 hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,

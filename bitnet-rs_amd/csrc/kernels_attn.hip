@@ -58,7 +58,26 @@ __device__ __forceinline__ float awave_sum(float v) {
 // run the chunk algorithm side by side and meet in LDS, so there is ONE record per 128 positions: half as many
 // records for whoever merges them (the combine kernel, or the o-projection at short contexts) and, at 4k keys, 160
 // workgroups instead of 320 (one per CU instead of 64 CUs with two).
-template <int NH>
+__device__ __forceinline__ float amix_lo(float a, uint32_t h, float c) {  // a * f16(h.lo) + c, no conversion instruction
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float amix_hi(float a, uint32_t h, float c) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+// KV16: the cache holds f16 (opt-in: half the bytes of the long-context stream; the reference's cache is f32 Tensor::cat,
+// T:1171-1202 -- values rounded ONCE, from the exact f32 k / v, when they are appended).  Layout then:
+// K [kv][chunk][D / 2][64 positions][2 dims] (a lane still reads 4 bytes per load: a dim PAIR of its position),
+// V [kv][pos][D] halves (a thread takes a dim pair of every 4th position).
+template <int NH, bool KV16>
 __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
                                                            const float *__restrict__ rope_cos, float *__restrict__ kcache,
                                                            float *__restrict__ vcache, int n_heads, int n_kv, int group, int max_pos,
@@ -73,10 +92,11 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
     __shared__ __attribute__((aligned(16))) float kn[kD];
     __shared__ float vn[kD];
     __shared__ float partial[NH][4][kAttnChunk][kMaxGroup];
-    __shared__ float red[NH][2 * kMaxGroup * kD];  // [half][position parity][head][dim] partial P.V sums
-    // softmax weights, stored [head][position parity][position / 2]: the P.V pass (a thread takes every
-    // second position) reads four of its positions per ds_read_b128 instead of one per ds_read_b32
-    __shared__ __attribute__((aligned(16))) float sc[NH][kMaxGroup][2][kAttnChunk / 2];
+    constexpr int NPQ = KV16 ? 4 : 2;  // position classes of the P.V pass (a thread takes every NPQ-th position)
+    __shared__ float red[NH][NPQ * kMaxGroup * kD];  // [half][position class][head][dim] partial P.V sums
+    // softmax weights, stored [head][position class][position / NPQ]: the P.V pass reads four of its positions per
+    // ds_read_b128 instead of one per ds_read_b32
+    __shared__ __attribute__((aligned(16))) float sc[NH][kMaxGroup][NPQ][kAttnChunk / NPQ];
     __shared__ __attribute__((aligned(16))) float enew[kMaxGroup];  // softmax weight of the new token (its half only)
     __shared__ float hm[NH][kMaxGroup], hl[NH][kMaxGroup];          // per-half (m, l) for the merge (NH == 2)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,8 +111,9 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
     // branch each: 64 of them were a third of this kernel's instructions).
     const bool last = live && t_k - j0 <= kAttnChunk;
     const float *sr = rope_sin + (size_t)pos * hd, *cr = rope_cos + (size_t)pos * hd;
-    float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos);  // [chunk][D][64]
-    float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos);  // [max_pos][D]
+    // f16 caches: the same element counts, half the bytes (the pointers are kept as float* in the f32 build only)
+    float *kt = kcache + (size_t)kvh * kv_head_floats(max_pos) / (KV16 ? 2 : 1);  // [chunk][D][64]   | f16: [chunk][D/2][64][2]
+    float *vc = vcache + (size_t)kvh * kv_head_floats(max_pos) / (KV16 ? 2 : 1);  // [max_pos][D]
     // ---- the few loads RoPE needs go first (vmcnt retires in order: behind the 64 cache loads they
     //      would only count as arrived once the whole K/V chunk has) ------------------------------------
     //      All unconditional (clamped indices): a load under a branch makes hipcc wait at the join.
@@ -108,17 +129,29 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
     //      lane offset + immediates, no clamping: the whole 64-position tile is inside the allocation (the cache
     //      is padded to whole chunks, and a dead half re-reads its workgroup's first tile); positions at or past
     //      the new token hold stale bytes, discarded below ----
-    float kv[32], vv[kAttnChunk / 2];
+    float kv[KV16 ? 1 : 32], vv[KV16 ? 1 : kAttnChunk / 2];
+    uint32_t kh[KV16 ? 16 : 1], vh[KV16 ? kAttnChunk / 4 : 1];  // f16 pairs: (dim 2i, 2i + 1) of the wave's slice / of the thread's dim pair
     {
         const int cl = live ? chunk : pc * NH, jl = cl * kAttnChunk;
-        const float *kp = kt + ((size_t)cl * kD + 32 * wave) * 64 + lane;  // kidx(32 * wave, jl + lane)
+        if (!KV16) {
+            const float *kp = kt + ((size_t)cl * kD + 32 * wave) * 64 + lane;  // kidx(32 * wave, jl + lane)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + i * 64);  // cache bytes are read once per token
-        // P.V: thread (d = t4 & 127, parity hp = t4 >> 7) takes positions jl + hp, jl + hp + 2, ...:
-        // element (jl + 2 i + hp) * D + d = jl * D + t4 + 2 i D
-        const float *vp = vc + (size_t)jl * kD + t4;
+            for (int i = 0; i < 32; ++i) kv[i] = __builtin_nontemporal_load(kp + i * 64);  // cache bytes are read once per token
+            // P.V: thread (d = t4 & 127, parity hp = t4 >> 7) takes positions jl + hp, jl + hp + 2, ...:
+            // element (jl + 2 i + hp) * D + d = jl * D + t4 + 2 i D
+            const float *vp = vc + (size_t)jl * kD + t4;
 #pragma unroll
-        for (int i = 0; i < kAttnChunk / 2; ++i) vv[i] = __builtin_nontemporal_load(vp + i * 2 * kD);
+            for (int i = 0; i < kAttnChunk / 2; ++i) vv[i] = __builtin_nontemporal_load(vp + i * 2 * kD);
+        } else {
+            // K: dword (dim pair 16 wave + i, position lane) of tile cl
+            const uint32_t *kp = reinterpret_cast<const uint32_t *>(kt) + ((size_t)cl * (kD / 2) + 16 * wave) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kh[i] = __builtin_nontemporal_load(kp + i * 64);
+            // P.V: thread (dim pair dp = t4 & 63, class pq = t4 >> 6) takes positions jl + pq + 4 i: dword (jl + pq + 4 i) * 64 + dp
+            const uint32_t *vp = reinterpret_cast<const uint32_t *>(vc) + (size_t)jl * (kD / 2) + t4;
+#pragma unroll
+            for (int i = 0; i < kAttnChunk / 4; ++i) vh[i] = __builtin_nontemporal_load(vp + i * 4 * (kD / 2));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep hipcc from moving the RoPE arithmetic (and its wait) up between the loads
     // ---- RoPE on the group's queries (and, in the owning half, on the new key) ----------
@@ -140,11 +173,22 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         kn[hd + rj] = b;
         vn[t4 & 127] = rv;
         if (last) {
-            if (t4 < hd) {
-                kt[kidx(t4, pos)] = a;  // append (transposed)
-                kt[kidx(hd + t4, pos)] = b;
-            } else if (t4 >= 128) {
-                vc[(size_t)pos * kD + (t4 - 128)] = rv;
+            if (!KV16) {
+                if (t4 < hd) {
+                    kt[kidx(t4, pos)] = a;  // append (transposed)
+                    kt[kidx(hd + t4, pos)] = b;
+                } else if (t4 >= 128) {
+                    vc[(size_t)pos * kD + (t4 - 128)] = rv;
+                }
+            } else {
+                _Float16 *k16 = reinterpret_cast<_Float16 *>(kt), *v16 = reinterpret_cast<_Float16 *>(vc);
+                if (t4 < hd) {  // element (d, pos) at ((chunk * 64 + d / 2) * 64 + pos % 64) * 2 + d % 2
+                    const size_t tb = (size_t)(pos >> 6) * (kD / 2), pp = pos & 63;
+                    k16[((tb + (t4 >> 1)) * 64 + pp) * 2 + (t4 & 1)] = (_Float16)a;
+                    k16[((tb + ((hd + t4) >> 1)) * 64 + pp) * 2 + (t4 & 1)] = (_Float16)b;
+                } else if (t4 >= 128) {
+                    v16[(size_t)pos * kD + (t4 - 128)] = (_Float16)rv;
+                }
             }
         }
     }
@@ -152,7 +196,33 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
     // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
     // Two partial sums per head (even / odd dims) so that each v_pk_fma_f32 takes an adjacent (q[d], q[d+1]) pair
     // from one LDS read and an adjacent (k[d], k[d+1]) register pair: no operand shuffling.
-    {
+    if (KV16) {
+        if (last) {  // the new token's key comes from LDS, rounded as the cache will hold it
+            const bool isnew = j0 + lane == pos;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                float4 k4 = *reinterpret_cast<const float4 *>(kn + 32 * wave + 2 * i);
+                asm volatile("" : "+v"(k4.x), "+v"(k4.y), "+v"(k4.z), "+v"(k4.w));
+                const uint32_t p0 = pack_h2(k4.x, k4.y), p1 = pack_h2(k4.z, k4.w);
+                kh[i] = isnew ? p0 : kh[i];
+                kh[i + 1] = isnew ? p1 : kh[i + 1];
+            }
+        }
+        float acc[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f}, acc2[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+#pragma unroll
+            for (int g = 0; g < kMaxGroup; ++g) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(qs + g * kD + 32 * wave + 2 * i);
+                acc[g] = amix_lo(q4.x, kh[i], acc[g]);
+                acc2[g] = amix_hi(q4.y, kh[i], acc2[g]);
+                acc[g] = amix_lo(q4.z, kh[i + 1], acc[g]);
+                acc2[g] = amix_hi(q4.w, kh[i + 1], acc2[g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) partial[half][wave][lane][g] = acc[g] + acc2[g];
+    } else {
         if (last) {  // the new token's key comes from LDS (its cache slot was read before it was written)
             const bool isnew = j0 + lane == pos;
 #pragma unroll
@@ -193,7 +263,10 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         const float e = j < t_k ? expf(s - m_c) : 0.0f;
         l_c = awave_sum(e);
         // the new token's value is not in the cache registers: its weight goes aside (enew) and its slot gets 0
-        sc[half][g][lane & 1][lane >> 1] = j == pos ? 0.0f : e;
+        if (KV16)
+            sc[half][g][lane & 3][lane >> 2] = j == pos ? 0.0f : e;
+        else
+            sc[half][g][lane & 1][lane >> 1] = j == pos ? 0.0f : e;
         if (j == pos) enew[g] = e;
         if (NH == 2 && lane == 0) {
             hm[half][g] = m_c;
@@ -203,7 +276,56 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
     __syncthreads();
     // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
-    {
+    if (KV16) {
+        const int dp = t4 & 63, pq = t4 >> 6;
+        float a0[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[kMaxGroup] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < kAttnChunk / 4; i += 4) {
+#pragma unroll
+            for (int g = 0; g < kMaxGroup; ++g) {
+                const float4 w = *reinterpret_cast<const float4 *>(&sc[half][g][pq][i]);
+                a0[g] = amix_lo(w.x, vh[i], a0[g]);
+                a1[g] = amix_hi(w.x, vh[i], a1[g]);
+                a0[g] = amix_lo(w.y, vh[i + 1], a0[g]);
+                a1[g] = amix_hi(w.y, vh[i + 1], a1[g]);
+                a0[g] = amix_lo(w.z, vh[i + 2], a0[g]);
+                a1[g] = amix_hi(w.z, vh[i + 2], a1[g]);
+                a0[g] = amix_lo(w.w, vh[i + 3], a0[g]);
+                a1[g] = amix_hi(w.w, vh[i + 3], a1[g]);
+            }
+        }
+        if (last && pq == 0) {  // the new token: value from LDS (rounded as the cache holds it), weight from enew
+            const float v0 = (float)(_Float16)vn[2 * dp], v1 = (float)(_Float16)vn[2 * dp + 1];
+            const float4 en = *reinterpret_cast<const float4 *>(enew);
+            a0[0] += en.x * v0, a1[0] += en.x * v1;
+            a0[1] += en.y * v0, a1[1] += en.y * v1;
+            a0[2] += en.z * v0, a1[2] += en.z * v1;
+            a0[3] += en.w * v0, a1[3] += en.w * v1;
+        }
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) {
+            red[half][(pq * kMaxGroup + g) * kD + 2 * dp] = a0[g];
+            red[half][(pq * kMaxGroup + g) * kD + 2 * dp + 1] = a1[g];
+        }
+        __syncthreads();
+        auto rsum = [&](int hf, int g, int d) {
+            return (red[hf][g * kD + d] + red[hf][(kMaxGroup + g) * kD + d]) + (red[hf][(2 * kMaxGroup + g) * kD + d] + red[hf][(3 * kMaxGroup + g) * kD + d]);
+        };
+        if (NH == 1) {
+            const int d = t4 & 127, hp = t4 >> 7;
+#pragma unroll
+            for (int g = 2 * hp; g < 2 * hp + 2; ++g) rec[2 * kMaxGroup + g * kD + d] = rsum(0, g, d);
+        } else {
+            const int g = tid >> 7, d = tid & 127;
+            const float m0 = hm[0][g], m1 = hm[1][g], M = fmaxf(m0, m1);
+            const float e0 = __expf(m0 - M), e1 = __expf(m1 - M);
+            rec[2 * kMaxGroup + g * kD + d] = e0 * rsum(0, g, d) + e1 * rsum(1, g, d);
+            if (d == 0) {
+                rec[2 * g] = M;
+                rec[2 * g + 1] = e0 * hl[0][g] + e1 * hl[1][g];
+            }
+        }
+    } else {
         const int d = t4 & 127, hp = t4 >> 7;
         // Cache slots at or past the new token hold stale bytes; their weights are exact zeros (the new token's own
         // goes through enew), and 0 * finite = 0: the caches must never hold NaN / Inf bit patterns, i.e. be
@@ -338,16 +460,13 @@ size_t attn_scratch_floats(int n_kv, int max_pos) {
 
 hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const float *rope_cos, float *kcache,
                               float *vcache, int n_heads, int n_kv, int D, int max_pos, const int *pos_ptr,
-                              float *scratch, float *out, hipStream_t stream, bool combine, int halves, void *qout) {
+                              float *scratch, float *out, hipStream_t stream, bool combine, int halves, void *qout, int kv_f16) {
     if (D != kD || n_heads / n_kv > kMaxGroup || (halves != 1 && halves != 2)) return hipErrorInvalidValue;
     const int rec_pos = kAttnChunk * halves;  // positions per record
     const int n_rec = (max_pos + rec_pos - 1) / rec_pos;
-    if (halves == 2)
-        hipLaunchKernelGGL(k_attn_partial<2>, dim3(n_kv, n_rec), dim3(512), 0, stream, qkv, rope_sin, rope_cos, kcache,
-                           vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
-    else
-        hipLaunchKernelGGL(k_attn_partial<1>, dim3(n_kv, n_rec), dim3(256), 0, stream, qkv, rope_sin, rope_cos, kcache,
-                           vcache, n_heads, n_kv, n_heads / n_kv, max_pos, pos_ptr, scratch);
+    auto kfn = halves == 2 ? (kv_f16 ? k_attn_partial<2, true> : k_attn_partial<2, false>) : (kv_f16 ? k_attn_partial<1, true> : k_attn_partial<1, false>);
+    hipLaunchKernelGGL(kfn, dim3(n_kv, n_rec), dim3(256 * halves), 0, stream, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, n_heads / n_kv,
+                       max_pos, pos_ptr, scratch);
     // combine == false: the chunk records stay in `scratch` for a consumer that merges them itself
     // (launch_gemv_mfma with GemvFusion::attn_rec)
     if (combine)

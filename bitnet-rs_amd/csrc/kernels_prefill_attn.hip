@@ -52,6 +52,7 @@ struct PrefillArgs {
     // of absolute position t is found here instead of by a scatter pass on the host side.  zz_world == 0: absolute order.
     int zz_world, zz_chunk;  // ranks, tokens per chunk (T = 2 * world * chunk; chunk % 64 == 0)
     int kv_f16;              // the k|v rows travelled as f16 (half the bytes on the wire); k / v then point at _Float16
+    int cache_f16;           // the decode caches hold f16 (kernels_attn.hip KV16 layout)
 };
 
 // row of absolute position t (a multiple of 64) in the gathered k|v buffer: chunk c = t / chunk belongs to rank c (first
@@ -119,16 +120,32 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
         // decode cache: K transposed in 64-position tiles [chunk][128][64] (kernels_attn.hip); t0 is a tile start
         const size_t head_floats = (size_t)((p.max_pos + 63) / 64) * 64 * kPD;
         float *kt = p.kcache + (size_t)kvh * head_floats + (size_t)(t0 >> 6) * kPD * 64;
-        for (int i = 0; i < 32 && p.kcache; ++i) {
-            const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
-            if (t0 + tok < p.T) kt[(size_t)d * 64 + tok] = tile[tok][d];
+        if (p.cache_f16) {  // [chunk][D / 2][64][2] halves
+            _Float16 *k16 = reinterpret_cast<_Float16 *>(p.kcache) + (size_t)kvh * head_floats + (size_t)(t0 >> 6) * kPD * 64;
+            for (int i = 0; i < 32 && p.kcache; ++i) {
+                const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
+                if (t0 + tok < p.T) k16[((size_t)(d >> 1) * 64 + tok) * 2 + (d & 1)] = (_Float16)tile[tok][d];
+            }
+        } else {
+            for (int i = 0; i < 32 && p.kcache; ++i) {
+                const int idx = tid + 256 * i, d = idx >> 6, tok = idx & 63;
+                if (t0 + tok < p.T) kt[(size_t)d * 64 + tok] = tile[tok][d];
+            }
         }
     } else {
         const int kvh = slot - p.n_heads - p.n_kv;
         float *vc = p.vcache + (size_t)kvh * ((size_t)((p.max_pos + 63) / 64) * 64 * kPD);  // [max_pos][128]
-        for (int i = 0; i < 32 && p.vcache; ++i) {
-            const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
-            if (t0 + tok < p.T) vc[(size_t)(t0 + tok) * kPD + d] = tile[tok][d];
+        if (p.cache_f16) {
+            _Float16 *v16 = reinterpret_cast<_Float16 *>(p.vcache) + (size_t)kvh * ((size_t)((p.max_pos + 63) / 64) * 64 * kPD);
+            for (int i = 0; i < 32 && p.vcache; ++i) {
+                const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+                if (t0 + tok < p.T) v16[(size_t)(t0 + tok) * kPD + d] = (_Float16)tile[tok][d];
+            }
+        } else {
+            for (int i = 0; i < 32 && p.vcache; ++i) {
+                const int idx = tid + 256 * i, tok = idx >> 7, d = idx & 127;
+                if (t0 + tok < p.T) vc[(size_t)(t0 + tok) * kPD + d] = tile[tok][d];
+            }
         }
         _Float16 *vt = p.vt + (size_t)kvh * kPD * p.Tpad;  // [128][Tpad]
         for (int i = 0; i < 32; ++i) {
@@ -288,7 +305,7 @@ size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
                                int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream,
-                               int zz_world, int kv_f16) {
+                               int zz_world, int kv_f16, int cache_f16) {
     if (D != kPD || T <= 0 || nq <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
     if (zz_world < 0 || (zz_world > 0 && (T % (2 * zz_world * kQB) != 0))) return hipErrorInvalidValue;
     if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, nq, T)) return hipErrorInvalidValue;
@@ -299,6 +316,7 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.zz_world = zz_world;
     p.zz_chunk = zz_world > 0 ? T / (2 * zz_world) : 0;
     p.kv_f16 = kv_f16;
+    p.cache_f16 = cache_f16;
     p.ld_q = ld_q;
     p.ld_kv = ld_kv;
     p.hs_q = p.hs_kv = kPD;
@@ -367,7 +385,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.causal = causal;
     p.scale = scale;
     p.q_block_pos = nullptr;
-    p.zz_world = p.zz_chunk = p.kv_f16 = 0;
+    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = 0;
     p.nq = seq;
     p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;

@@ -74,6 +74,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
     }
     if (const char *e = getenv("BITNET_HOST_LOGITS_WGS")) logits_wgs_ = atoi(e) > 0 ? atoi(e) : logits_wgs_;  // tuning knob
     if (const char *e = getenv("BITNET_TRACE_DIR")) trace_dir_ = e;  // the reference's switch (crates/bitnet-trace/src/lib.rs:113-117)
+    if (const char *e = getenv("BITNET_HOST_KV16")) kv_f16_ = atoi(e) != 0;  // opt-in f16 KV cache (long contexts)
     if (const char *e = getenv("BITNET_HOST_ACT")) act_mode_ = atoi(e) != 0 ? 1 : 0;  // 0: exact f32 activations between the kernels
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
@@ -359,6 +360,32 @@ int Decoder::position() {
     return p;
 }
 
+// The decode attention in the form and cache type this decoder runs: form 0 two kernels (64-position records), 1 records only
+// (the o-projection merges them), 2 two kernels with 128-position records; out / qout: f32 output and / or its QAct.
+int Decoder::attn_launch(Layer &L, int form, float *out, void *qout) {
+    const int flags = (form == 2 ? BITNET_HIP_ATTN_WIDE : 0) | (form == 1 ? BITNET_HIP_ATTN_PARTIAL : 0) | (kv_f16_ ? BITNET_HIP_ATTN_KV_F16 : 0);
+    BCHK(bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,
+                                           (size_t)c_.max_pos, pos_, attn_scratch_, flags, out, qout, stream_));
+    return 0;
+}
+
+int Decoder::set_kv_f16(bool on) {
+    if (position() != 0 || host_forced_ != 0) {
+        err_ = "set_kv_f16: only on a fresh sequence (reset() first): a cache is f16 or f32 for its whole life";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if (on != kv_f16_) {
+        drop_graphs();
+        for (auto &L : layers_) {  // stale bytes of the other type could be NaN / Inf patterns in this one
+            const size_t n = (size_t)c_.n_kv_heads * (((size_t)c_.max_pos + 63) / 64 * 64) * c_.head_dim;
+            HCHK(hipMemset(L.kcache, 0, n * sizeof(float)));
+            HCHK(hipMemset(L.vcache, 0, n * sizeof(float)));
+        }
+    }
+    kv_f16_ = on;
+    return 0;
+}
+
 // Reads a device f32 vector back after the kernel that wrote it and leaves one trace record (reference format).
 struct Decoder::Tracer {
     std::string dir;
@@ -418,11 +445,10 @@ int Decoder::step_launches(bool with_logits, int form, Tracer *tr) {
             TRACE(bp + "k_proj", "k_proj", (int)l, qkv_ + tQD, tKD);
             TRACE(bp + "v_proj", "v_proj", (int)l, qkv_ + tQD + tKD, tKD);
             if (form == 1) {
-                BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, s));
+                if (int rc = attn_launch(L, 1, nullptr, nullptr)) return rc;
                 BCHK(bitnet_hip_gemv_attn_merge_q_dev(L.o, attn_scratch_, NH, NK, MP, pos_, x2_, x_, qa_x2_, L.ffn_norm, st_x2_, s));
             } else {
-                BCHK(bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, form == 2 ? 1 : 0,
-                                                       tr ? att_ : nullptr, qa_att_, s));
+                if (int rc = attn_launch(L, form, tr ? att_ : nullptr, qa_att_)) return rc;
                 TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
                 BCHK(bitnet_hip_gemv_q_dev(L.o, qa_att_, nullptr, nullptr, 0.f, x_, 0, x2_, qa_x2_, L.ffn_norm, st_x2_, s));
             }
@@ -455,18 +481,15 @@ int Decoder::step_launches(bool with_logits, int form, Tracer *tr) {
         TRACE(bp + "k_proj", "k_proj", (int)l, qkv_ + tQD, tKD);
         TRACE(bp + "v_proj", "v_proj", (int)l, qkv_ + tQD + tKD, tKD);
         if (form == 2) {
-            BCHK(bitnet_hip_attention_decode_wide_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                                      (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            if (int rc = attn_launch(L, 2, att_, nullptr)) return rc;
             TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
             BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
         } else if (form == 1) {
             // short contexts: one attention launch; the o-projection merges the chunk records itself
-            BCHK(bitnet_hip_attention_decode_partial_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                                         (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, s));
+            if (int rc = attn_launch(L, 1, nullptr, nullptr)) return rc;
             BCHK(bitnet_hip_gemv_attn_merge_dev(L.o, attn_scratch_, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.max_pos, pos_, x2_, x_, s));
         } else {
-            BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                                 (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+            if (int rc = attn_launch(L, 0, att_, nullptr)) return rc;
             TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
             // o_proj + residual (T:542, T:1073)
             BCHK(bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, s));
@@ -532,8 +555,7 @@ int Decoder::step_launches_reference(bool with_logits) {
     for (auto &L : layers_) {
         BCHK(bitnet_hip_norm_rows_dev(x_, L.attn_norm, ref_n_, 1, H, c_.eps, 0, s));
         BCHK(bitnet_hip_matmul_kernel_dev(L.qkv, ref_n_, qkv_, 1, K, s));
-        BCHK(bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
-                                             (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, s));
+        if (int rc = attn_launch(L, 0, att_, nullptr)) return rc;
         BCHK(bitnet_hip_matmul_kernel_dev(L.o, att_, ref_t_, 1, K, s));
         BCHK(bitnet_hip_add_dev(x_, ref_t_, x2_, H, s));
         BCHK(bitnet_hip_norm_rows_dev(x2_, L.ffn_norm, ref_n_, 1, H, c_.eps, 0, s));
@@ -704,8 +726,12 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, N, H, (size_t)c_.vocab, pf_x_, s));  // *pos_ == 0
     for (auto &L : layers_) {
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
-        BCHK(bitnet_hip_attention_prefill_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
-                                              (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+        if (kv_f16_)
+            BCHK(bitnet_hip_attention_prefill_kv16_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                                       (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+        else
+            BCHK(bitnet_hip_attention_prefill_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                                  (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
@@ -821,7 +847,7 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
             return BITNET_HIP_ERR_EXECUTION;
         }
         BCHK(bitnet_hip_attention_prefill_gathered_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
-                                                       rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+                                                       rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
@@ -906,7 +932,7 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
             const bool more = li + 1 < layers_.size();
             switch (kind) {
                 case 0: rc = bitnet_hip_gemv_q_dev(L.qkv, qa_x_, st_x_, L.attn_norm, c_.eps, nullptr, 0, qkv_, nullptr, nullptr, nullptr, stream_); break;
-                case 1: rc = bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, NH, NK, D, MP, pos_, attn_scratch_, 0, nullptr, qa_att_, stream_); break;
+                case 1: rc = attn_launch(L, form_at(p0 > 0 ? p0 : 0) == 2 ? 2 : 0, nullptr, qa_att_); break;
                 case 2: rc = bitnet_hip_gemv_q_dev(L.o, qa_att_, nullptr, nullptr, 0.f, x_, 0, x2_, qa_x2_, L.ffn_norm, st_x2_, stream_); break;
                 case 3: rc = bitnet_hip_gemv_q_dev(L.gateup, qa_x2_, st_x2_, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, nullptr, qa_h_, nullptr, nullptr, stream_); break;
                 default:
@@ -921,10 +947,7 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
         }
         switch (kind) {
             case 0: rc = bitnet_hip_gemv_fused_dev(L.qkv, x_, qkv_, 1, L.attn_norm, c_.eps, nullptr, 0, stream_); break;
-            case 1:
-                rc = bitnet_hip_attention_decode_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads,
-                                                     (size_t)c_.n_kv_heads, (size_t)c_.head_dim, (size_t)c_.max_pos, pos_, attn_scratch_, att_, stream_);
-                break;
+            case 1: rc = attn_launch(L, form_at(p0 > 0 ? p0 : 0) == 2 ? 2 : 0, att_, nullptr); break;
             case 2: rc = bitnet_hip_gemv_fused_dev(L.o, att_, x2_, 1, nullptr, 0.f, x_, 0, stream_); break;
             case 3: rc = bitnet_hip_gemv_fused_dev(L.gateup, x2_, h_, 1, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, stream_); break;
             case 4: rc = bitnet_hip_gemv_fused_dev(L.down, h_, x_, 1, nullptr, 0.f, x2_, 0, stream_); break;
@@ -964,7 +987,7 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
     if (bytes_per_launch) {
         size_t ab = 0;
         const Layer &L = layers_[0];
-        const double kv = 2.0 * c_.n_kv_heads * (double)(position() + 1) * c_.head_dim * 4;
+        const double kv = 2.0 * c_.n_kv_heads * (double)(position() + 1) * c_.head_dim * (kv_f16_ ? 2 : 4);
         if (qp && kind <= 4 && kind != 1) {
             // QAct path: codes + scales + the activation records read (+ statistics pairs) + what the launch writes
             const double qH = (double)bitnet_hip_qact_bytes(H), qF = (double)bitnet_hip_qact_bytes((size_t)c_.ffn), sH = (double)bitnet_hip_qact_stats_bytes(H);
@@ -1043,6 +1066,7 @@ int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *fin
 }
 int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
 int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
+int bitnet_host_set_kv_f16(void *d, int on) { return static_cast<Decoder *>(d)->set_kv_f16(on != 0); }
 int bitnet_host_set_act_mode(void *d, int mode) { return static_cast<Decoder *>(d)->set_act_mode(mode); }
 int bitnet_host_act_mode(void *d) { return static_cast<Decoder *>(d)->qact_path() ? 1 : 0; }
 int bitnet_host_run_reference(void *d, int n, int with_logits) { return static_cast<Decoder *>(d)->run_reference(n, with_logits != 0); }

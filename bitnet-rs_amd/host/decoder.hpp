@@ -91,6 +91,10 @@ class Decoder {
     // Activations between the step's kernels: 1 (default) = quantised once by their producer ("QAct", include/bitnet_hip.h:
     // the f16-class activation north_star names), 0 = exact f32 (round 1's kernels).  Env BITNET_HOST_ACT sets the default.
     int set_act_mode(int mode);
+    // Opt-in f16 KV cache (half the bytes of the long-context decode stream; the reference's cache is f32, T:1171-1202): k / v are
+    // rounded once, when appended.  Only on a fresh sequence.  Env BITNET_HOST_KV16 sets the default.
+    int set_kv_f16(bool on);
+    bool kv_f16() const { return kv_f16_; }
     bool qact_path() const;  // mode 1 AND every layer's matrices are on that path
     // Whole-prompt forward on a fresh sequence (position() == 0): the first n fed tokens go
     // through every layer as [n, *] matrices (TransformerModel::forward with seq_len n,
@@ -153,6 +157,7 @@ class Decoder {
         float *kcache = nullptr, *vcache = nullptr;
         bool q_ok = false;  // all four matrices take QAct inputs (bitnet_hip_gemv_q_supported)
     };
+    int attn_launch(Layer &L, int form, float *out, void *qout);
     void release_layer(Layer &L);  // frees the layer's handles, subtracts their bytes, drops the captured graphs
     void drop_graphs();
     int adopt_projections(Layer &L, bitnet_hip_weights_t h[7]);
@@ -164,6 +169,7 @@ class Decoder {
     void *qa_x_ = nullptr, *qa_x2_ = nullptr, *qa_att_ = nullptr, *qa_h_ = nullptr;  // QAct records of x, x2, attention output, silu(gate)*up
     double *st_x_ = nullptr, *st_x2_ = nullptr;                                       // LayerNorm statistics pairs of x, x2
     int act_mode_ = 1;
+    bool kv_f16_ = false;
     std::string trace_dir_;  // BITNET_TRACE_DIR at construction
     float *ref_n_ = nullptr, *ref_gu_ = nullptr, *ref_t_ = nullptr;  // unfused reference step: normalised row, gate|up tiles, projection out
     void *scratch_ = nullptr;
@@ -208,6 +214,7 @@ int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
 int bitnet_host_run_reference(void *d, int n, int with_logits);
 int bitnet_host_set_act_mode(void *d, int mode);
+int bitnet_host_set_kv_f16(void *d, int on);
 int bitnet_host_act_mode(void *d);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);

@@ -357,10 +357,21 @@ int bitnet_hip_gemv_q_dev(bitnet_hip_weights_t w, const void *qact_in, const dou
                           float *y_dev, void *qact_out, const float *gamma_out_dev, double *stats_out, void *stream);
 /* bitnet_hip_attention_decode[_wide]_dev whose combine step also (or only: out_dev NULL) leaves the QAct of the
  * attention output for the o-projection */
+#define BITNET_HIP_ATTN_WIDE 1    /* 128-position workgroups (bitnet_hip_attention_decode_wide_dev) */
+#define BITNET_HIP_ATTN_KV_F16 2  /* the caches hold f16: HALF the bytes of the long-context stream.  Opt-in: the reference's cache is f32
+                                   * (T:1171-1202); values are rounded once, from the exact f32 k / v, when appended.  Same element
+                                   * counts as the f32 caches, half the allocation; zero-fill before first use likewise.  A cache is
+                                   * f16 or f32 for its whole life: fill it with bitnet_hip_attention_prefill_kv16_dev / cache_f16 = 1. */
+#define BITNET_HIP_ATTN_PARTIAL 4 /* chunk records only (bitnet_hip_attention_decode_partial_dev): out_dev and qact_out unused */
 int bitnet_hip_attention_decode_q_dev(const float *qkv_dev, const float *rope_sin_dev, const float *rope_cos_dev,
-                                      float *kcache_dev, float *vcache_dev, size_t n_heads, size_t n_kv_heads,
+                                      void *kcache_dev, void *vcache_dev, size_t n_heads, size_t n_kv_heads,
                                       size_t head_dim, size_t max_pos, const int32_t *pos_dev, float *scratch_dev,
-                                      int wide, float *out_dev, void *qact_out, void *stream);
+                                      int flags, float *out_dev, void *qact_out, void *stream);
+/* bitnet_hip_attention_prefill_dev filling f16 decode caches */
+int bitnet_hip_attention_prefill_kv16_dev(const float *qkv_dev, const float *rope_sin_dev, const float *rope_cos_dev,
+                                          void *kcache_f16_dev, void *vcache_f16_dev, size_t n_heads, size_t n_kv_heads,
+                                          size_t head_dim, size_t max_pos, size_t seq_len, void *workspace_dev,
+                                          size_t workspace_bytes, float *out_dev, void *stream);
 /* bitnet_hip_gemv_attn_merge_dev (short contexts) with the QAct outputs of gemv_q_dev */
 int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
                                      size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
@@ -402,10 +413,10 @@ int bitnet_hip_attention_prefill_sharded_dev(const float *q_dev, size_t ld_q, co
  * columns [col0, col0 + ncols) of `rows` f32 rows, compact, as f32 or f16. */
 int bitnet_hip_attention_prefill_gathered_dev(const float *q_dev, size_t ld_q, const int32_t *q_block_pos_dev, size_t n_q,
                                               const void *kv_gathered_dev, size_t n_ctx, size_t world, int kv_is_f16,
-                                              const float *rope_sin_dev, const float *rope_cos_dev, float *kcache_dev,
-                                              float *vcache_dev, size_t n_heads, size_t n_kv_heads, size_t head_dim,
-                                              size_t max_pos, void *workspace_dev, size_t workspace_bytes, float *out_dev,
-                                              void *stream);
+                                              const float *rope_sin_dev, const float *rope_cos_dev, void *kcache_dev,
+                                              void *vcache_dev, int cache_f16, size_t n_heads, size_t n_kv_heads,
+                                              size_t head_dim, size_t max_pos, void *workspace_dev, size_t workspace_bytes,
+                                              float *out_dev, void *stream);
 int bitnet_hip_pack_cols_dev(const float *src_dev, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst_dev,
                              int as_f16, void *stream);
 /* bytes of scratch_dev attention_decode_dev needs (per-chunk softmax partials) */

@@ -373,3 +373,93 @@ def test_decode_is_bit_reproducible_run_to_run(hip, pkg, synth):
     assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
     assert np.array_equal(runs[0][0], runs[2][0]) and runs[0][1] == runs[2][1]
     dec.close()
+
+
+@pytest.mark.parametrize("max_pos,positions,n_heads,n_kv,wide", [(512, [0, 1, 63, 64, 65, 127, 128, 300, 511], 8, 2, False), (512, [0, 64, 191], 3, 3, False),
+                                                                (8192, [0, 100, 3071, 3072, 5000, 8100], 8, 2, True), (4608, [4100, 4223, 4224], 20, 5, True)])
+def test_attention_decode_f16_kv_vs_f64(hip, oracle, torch_, max_pos, positions, n_heads, n_kv, wide):
+    """BITNET_HIP_ATTN_KV_F16: the cache holds f16 (K [kv][chunk][64 dim pairs][64 positions][2], V [kv][pos][128]), k / v are
+    rounded once when appended.  Against a f64 reference that uses the SAME f16 values: the arithmetic (f32 accumulate) is as
+    tight as the f32-cache kernel's."""
+    D = 128
+    group = n_heads // n_kv
+    rng = np.random.default_rng(max_pos + n_heads + 1)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    kc = rng.normal(0, 1, (n_kv, D, max_pos)).astype(np.float16)   # logical [kv][D][pos]
+    vc = rng.normal(0, 1, (n_kv, max_pos, D)).astype(np.float16)
+    ktile = lambda a: np.ascontiguousarray(a.reshape(n_kv, D // 2, 2, max_pos // 64, 64).transpose(0, 3, 1, 4, 2))   # [kv][chunk][D/2][64][2]
+    kuntile = lambda a: a.reshape(n_kv, max_pos // 64, D // 2, 64, 2).transpose(0, 2, 4, 1, 3).reshape(n_kv, D, max_pos)
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a)).cuda()
+    sb = hip.c.bitnet_hip_attention_scratch_bytes(n_kv, max_pos)
+    scratch = torch_.zeros(sb // 4 + 16, device="cuda")
+    sin_d, cos_d = dev(sin), dev(cos)
+    for pos in positions:
+        qkv = rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32)
+        kc_in, vc_in = kc.copy(), vc.copy()
+        kc_in[:, :, pos:] = np.float16(7.0)     # stale slots: finite bit patterns (zero-filled-cache contract)
+        vc_in[:, pos:] = np.float16(-300.0)
+        kcd, vcd = dev(ktile(kc_in).view(np.int16)), dev(vc_in.view(np.int16))
+        out = torch_.full((n_heads * D,), float("nan"), device="cuda")
+        pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
+        hip.attention_decode_q_dev(dev(qkv), sin_d, cos_d, kcd, vcd, n_heads, n_kv, D, max_pos, pos_d, scratch, out, None, wide=wide, kv_f16=True)
+        torch_.cuda.synchronize()
+        got = out.cpu().numpy().reshape(n_heads, D)
+        rot = lambda x: np.concatenate([x[..., :64] * cos[pos] - x[..., 64:] * sin[pos], x[..., :64] * sin[pos] + x[..., 64:] * cos[pos]], axis=-1)
+        q = rot(qkv[: n_heads * D].reshape(n_heads, D).astype(np.float64))
+        kn32 = rot(qkv[n_heads * D:(n_heads + n_kv) * D].reshape(n_kv, D).astype(np.float32))      # RoPE in f32 on the device
+        kn = rot(qkv[n_heads * D:(n_heads + n_kv) * D].reshape(n_kv, D).astype(np.float64)).astype(np.float32).astype(np.float16).astype(np.float64)
+        vn = qkv[(n_heads + n_kv) * D:].reshape(n_kv, D).astype(np.float16).astype(np.float64)
+        want = np.zeros((n_heads, D))
+        for h in range(n_heads):
+            kvh = h // group
+            K = np.concatenate([kc[kvh, :, :pos].T.astype(np.float64), kn[kvh][None]], axis=0)
+            V = np.concatenate([vc[kvh, :pos].astype(np.float64), vn[kvh][None]], axis=0)
+            s = K @ q[h] / np.sqrt(D)
+            p = np.exp(s - s.max())
+            want[h] = (p / p.sum()) @ V
+        # (the new key's f16 rounding can flip one ulp against this f64-then-f16 reference: 1e-3 of an O(1) score at most)
+        assert np.max(np.abs(got - want)) <= 2e-3 * max(1.0, np.abs(want).max()), (max_pos, pos, np.max(np.abs(got - want)))
+        # appended: the new key / value, rounded to f16, at `pos`
+        kback = kuntile(kcd.cpu().numpy().view(np.float16))
+        assert np.allclose(kback[:, :, pos].astype(np.float32), kn32, atol=2e-2, rtol=2e-3)
+        assert np.array_equal(vcd.cpu().numpy().view(np.float16).reshape(n_kv, max_pos, D)[:, pos], qkv[(n_heads + n_kv) * D:].reshape(n_kv, D).astype(np.float16))
+        # untouched neighbours
+        if pos > 0:
+            assert np.array_equal(kback[:, :, pos - 1], kc[:, :, pos - 1])
+
+
+def test_decode_with_f16_kv_cache_at_2k_keys_vs_oracle(hip, pkg, oracle, synth):
+    """opt-in f16 KV cache -- a 2,048-token prompt through Decoder.prefill (cache filled with the f16-rounded
+    k / v), then decode steps at 2k+ keys through the 128-position chunk form, per-step logits against the oracle (f32 cache):
+    cosine >= 0.9999; the same steps with the f32 cache for comparison."""
+    cfg = synth.ModelConfig(**dict(SMALL, max_pos=2240))
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    T, n_dec = 2048, 6
+    seq = list(synth.prompt(T + n_dec, cfg.vocab))
+    om = oracle.OracleModel(cfg, layers, glob, n_threads=8)
+    o_logits = []
+    for p in range(T + n_dec - 1):
+        _, logits, _ = om.step(seq[p], want_logits=p >= T - 1)
+        if p >= T - 1:
+            o_logits.append(logits)
+    om.close()
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w)
+    dec.set_globals(glob)
+    worst = {}
+    for kv16 in (True, False):
+        dec.reset()
+        dec.set_kv_f16(kv16)
+        dec.feed(seq)
+        dec.prefill(T, with_logits=True, digits=4)
+        cs = [cosine(dec.last_logits(), o_logits[0])]
+        for i in range(1, n_dec):
+            dec.run(1, with_logits=True, use_graph=True)
+            cs.append(cosine(dec.last_logits(), o_logits[i]))
+        worst[kv16] = min(cs)
+        assert min(cs) >= 0.9999, (kv16, cs)
+    with pytest.raises(pkg.BitNetHipError, match="fresh sequence"):
+        dec.set_kv_f16(True)
+    dec.close()
