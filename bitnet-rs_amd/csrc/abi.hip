@@ -782,6 +782,22 @@ static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_dev: matrix shape %zux%zu not supported", w->rows, w->cols);
     if (qact_out && w->rows % 16 != 0)
         return set_error(BITNET_HIP_ERR_UNSUPPORTED, "gemv_attn_merge_q_dev: rows %zu must be a multiple of 16 for a QAct output", w->rows);
+    if (qact_out && gemvq_supported(*w) && w->cols <= 4096) {
+        // QAct consumer form: the workgroup merges the records and quantises them once, into its LDS image (kernels_gemvq.hip MRG)
+        GemvQIo io;
+        io.residual = residual_dev;
+        io.y = y_dev;
+        io.qout = qact_out;
+        io.gamma_out = gamma_out_dev;
+        io.stats_out = stats_out;
+        io.attn_rec = attn_scratch_dev;
+        io.attn_pos = pos_dev;
+        io.attn_chunks_max = (int)div_ceil(max_pos, (size_t)64);
+        io.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
+        hipError_t e = launch_gemv_q(*w, io, (hipStream_t)stream);
+        if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+        return BITNET_HIP_OK;
+    }
     GemvFusion fu;
     fu.residual = residual_dev;
     fu.attn_rec = attn_scratch_dev;

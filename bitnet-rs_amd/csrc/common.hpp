@@ -114,6 +114,10 @@ struct GemvQIo {
     void *qout = nullptr;              // QAct output (nullable) ...
     const float *gamma_out = nullptr;  // ... multiplied by the NEXT LayerNorm's weight first (nullable)
     double *stats_out = nullptr;       // ... with its row statistics (nullable)
+    // instead of qin: the decode attention's chunk records, merged by the GEMV itself (short contexts, <= 4 records)
+    const float *attn_rec = nullptr;
+    const int *attn_pos = nullptr;
+    int attn_chunks_max = 0, attn_group_log2 = 0;
 };
 
 // ---- kernel launchers (kernels_*.hip) -------------------------------------

@@ -383,6 +383,11 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
 // One workgroup per head: 8 thread groups walk the chunk records in parallel (chunk c -> group
 // c % 8), each merging (m, l, o) online; the 8 partial states meet through LDS.  Threads of a
 // group take 4 dims each (float4: one 512-byte record row per group and step).
+// NR = records per thread group requested UP FRONT, before the position (hence the live record count) is known: the
+// records were written by other CUs' workgroups, so every dependent trip is a cross-XCD miss (~0.7-1 us); with
+// 8 * NR >= n_chunks_max the whole merge is ONE round trip.  Records past the context are valid memory (the scratch buffer
+// is sized for max_pos and zero-filled once) and are dropped by their index.
+template <int NR>
 __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ scratch, int n_kv, int group,
                                                       int n_chunks_max, int chunk_log2, const int *__restrict__ pos_ptr,
                                                       float *__restrict__ out, uint8_t *__restrict__ qout) {
@@ -392,39 +397,55 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float *__restrict__ 
     __shared__ float sm[8], sl[8];
     __shared__ __attribute__((aligned(16))) float sa[8][kD];
     const float *base = scratch + (size_t)kvh * n_chunks_max * kRec;
-    // the first record of every thread group is requested before the position is known (one dependent round trip
-    // less); a group without a chunk reads a valid but stale record and drops it below
-    const float *rec0 = base + (size_t)(part < n_chunks_max ? part : n_chunks_max - 1) * kRec;
-    const float mc0 = rec0[2 * g], lc0 = rec0[2 * g + 1];
-    const float4 o0 = *reinterpret_cast<const float4 *>(rec0 + 2 * kMaxGroup + g * kD + 4 * d4);
+    float mc[NR], lc[NR];
+    float4 o[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int c = part + 8 * u;
+        const float *rec = base + (size_t)(c < n_chunks_max ? c : n_chunks_max - 1) * kRec;
+        mc[u] = rec[2 * g];
+        lc[u] = rec[2 * g + 1];
+        o[u] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
+    }
     const int t_k = *pos_ptr + 1;
     const int n_chunks = (t_k + (1 << chunk_log2) - 1) >> chunk_log2;  // records of 64 or 128 positions
-    const bool has = part < n_chunks;
-    float m = has ? mc0 : -INFINITY, l = has ? lc0 : 0.0f;
-    float4 a = {has ? o0.x : 0.f, has ? o0.y : 0.f, has ? o0.z : 0.f, has ? o0.w : 0.f};
-    // long contexts: four further records per trip, all twelve loads requested before the first merge (a trip
-    // per record is a dependent L2 round trip each: 64 chunks at 4k context = 7 more rounds per group)
-    for (int c = part + 8; c < n_chunks; c += 32) {
-        float mc[4], lc[4];
-        float4 o[4];
+    float m = -INFINITY, l = 0.0f;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        if (part + 8 * u < n_chunks) {  // records merge in index order: the same value whatever NR is
+            const float m_new = fmaxf(m, mc[u]);
+            const float s_old = expf(m - m_new), s_c = expf(mc[u] - m_new);
+            l = l * s_old + lc[u] * s_c;
+            a.x = a.x * s_old + o[u].x * s_c;
+            a.y = a.y * s_old + o[u].y * s_c;
+            a.z = a.z * s_old + o[u].z * s_c;
+            a.w = a.w * s_old + o[u].w * s_c;
+            m = m_new;
+        }
+    }
+    // contexts beyond 8 * NR records: further trips, four records each
+    for (int c = part + 8 * NR; c < n_chunks; c += 32) {
+        float mc2[4], lc2[4];
+        float4 o2[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cu = c + 8 * u < n_chunks ? c + 8 * u : c;  // past the end: re-read this trip's first record, dropped below
             const float *rec = base + (size_t)cu * kRec;
-            mc[u] = rec[2 * g];
-            lc[u] = rec[2 * g + 1];
-            o[u] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
+            mc2[u] = rec[2 * g];
+            lc2[u] = rec[2 * g + 1];
+            o2[u] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroup + g * kD + 4 * d4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (c + 8 * u < n_chunks) {
-                const float m_new = fmaxf(m, mc[u]);
-                const float s_old = expf(m - m_new), s_c = expf(mc[u] - m_new);
-                l = l * s_old + lc[u] * s_c;
-                a.x = a.x * s_old + o[u].x * s_c;
-                a.y = a.y * s_old + o[u].y * s_c;
-                a.z = a.z * s_old + o[u].z * s_c;
-                a.w = a.w * s_old + o[u].w * s_c;
+                const float m_new = fmaxf(m, mc2[u]);
+                const float s_old = expf(m - m_new), s_c = expf(mc2[u] - m_new);
+                l = l * s_old + lc2[u] * s_c;
+                a.x = a.x * s_old + o2[u].x * s_c;
+                a.y = a.y * s_old + o2[u].y * s_c;
+                a.z = a.z * s_old + o2[u].z * s_c;
+                a.w = a.w * s_old + o2[u].w * s_c;
                 m = m_new;
             }
         }
@@ -469,9 +490,11 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
                        max_pos, pos_ptr, scratch);
     // combine == false: the chunk records stay in `scratch` for a consumer that merges them itself
     // (launch_gemv_mfma with GemvFusion::attn_rec)
-    if (combine)
-        hipLaunchKernelGGL(k_attn_combine, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_rec,
-                           halves == 2 ? 7 : 6, pos_ptr, out, static_cast<uint8_t *>(qout));
+    if (combine) {
+        auto cfn = n_rec <= 8 ? k_attn_combine<1> : n_rec <= 16 ? k_attn_combine<2> : n_rec <= 40 ? k_attn_combine<5> : k_attn_combine<8>;
+        hipLaunchKernelGGL(cfn, dim3(n_kv, n_heads / n_kv), dim3(256), 0, stream, scratch, n_kv, n_heads / n_kv, n_rec, halves == 2 ? 7 : 6, pos_ptr, out,
+                           static_cast<uint8_t *>(qout));
+    }
     return hipGetLastError();
 }
 

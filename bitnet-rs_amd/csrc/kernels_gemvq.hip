@@ -32,6 +32,7 @@ namespace bitnet_hip {
 
 namespace {
 
+constexpr int kMaxGroupQ = 4;  // query heads per KV head in an attention chunk record (kAttnRecFloats = 2 * 4 + 4 * 128)
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
@@ -109,6 +110,11 @@ struct GemvQArgs {
     uint8_t *qout;           // optional QAct output (for the next GEMV)
     const float *gamma_out;  // optional: the next GEMV's LayerNorm weight (u = v * gamma)
     double *stats_out;       // optional: (sum, sum of squares) per 16 output rows
+    // MRG: the activation vector is the decode attention's output, assembled HERE from its per-chunk records
+    // (launch_attn_decode(..., combine = false): (m, l)[4] + un-normalised P.V [4][128] per KV head and 64-position chunk)
+    const float *attn_rec;
+    const int *attn_pos;     // *attn_pos + 1 keys
+    int attn_chunks_max, attn_group_log2;
     unsigned long long *stamps;  // diagnostic builds only
 };
 
@@ -123,9 +129,15 @@ struct GemvQArgs {
 // (g_r, residual, the next LayerNorm's gamma) are requested up front too -- behind the barrier they were dependent
 // L2 / HBM round trips (0.7-0.8 us of a 2.5 us kernel).
 // Every global load is unconditional and sits ahead of a scheduling fence (kernels_mfma.hip explains why).
-template <int NW, int RING, int SC, int LN, int NCP>
+// MRG = NE > 0: short contexts (<= 4 chunk records): instead of copying QAct records the workgroup merges the attention's
+// chunk records itself -- thread t the elements t, t + NT, ... (NE of them) of the attention output: softmax merge of up to
+// 4 records, then the 16-lane group quantisation of qact.hpp straight into the LDS image.  One launch (k_attn_combine) and
+// one global round trip of the vector less per layer; every workgroup reads every live record (n_chunks x 10 KB), which
+// is why the decoder takes this form up to 256 keys only.
+template <int NW, int RING, int SC, int LN, int NCP, int NE = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
     constexpr int NT = NW * 64;
+    constexpr bool MRG = NE > 0;
     constexpr int ZB = RING * kQRec;  // zero bytes the dead A lanes read (no masking instructions)
     // every kernel argument in ONE scalar-load round: left alone hipcc fetches some of them where they are first used,
     // each a dependent round trip on the path to the first vector load
@@ -154,8 +166,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
     // ---- 1. the activation vector (L2-resident, every workgroup reads it), statistics pairs, epilogue operands ----
     const uint32_t q_last = (uint32_t)kQRec * (uint32_t)p.nblk - 16u;
     v4u qa[NCP];  // native vectors: arrays of HIP's uint4 struct went through scratch memory at the scheduling fence
+    float4 mo[MRG ? NE : 1][4];   // MRG: un-normalised P.V values of this thread's NE 4-element slots, chunks 0..3
+    float2 mml[MRG ? NE : 1][4];  //      and their heads' (m, l)
+    if (!MRG) {
 #pragma unroll
-    for (int i = 0; i < NCP; ++i) qa[i] = *reinterpret_cast<const v4u *>(p.qin + umin32q(16u * (uint32_t)(tid + NT * i), q_last));
+        for (int i = 0; i < NCP; ++i) qa[i] = *reinterpret_cast<const v4u *>(p.qin + umin32q(16u * (uint32_t)(tid + NT * i), q_last));
+    } else {
+        // chunks 0..3 are requested before the position (hence the live chunk count) is known; dead records hold zeros or
+        // an earlier token's finite values: only their m is masked below.  A thread takes 4 consecutive elements (one
+        // 16-byte load per chunk); a wave's 256 elements lie in at most two heads, whose (m, l) pairs every lane fetches.
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            int e = 4 * (tid + NT * i);
+            e = e < p.cols ? e : p.cols - 4;
+            const int h = e >> 7, d = e & 127, kvh = h >> p.attn_group_log2, hg = h & ((1 << p.attn_group_log2) - 1);
+            const float *rb = p.attn_rec + (size_t)kvh * p.attn_chunks_max * kAttnRecFloats;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float *rec = rb + (size_t)(c < p.attn_chunks_max ? c : p.attn_chunks_max - 1) * kAttnRecFloats;
+                mml[i][c] = *reinterpret_cast<const float2 *>(rec + 2 * hg);
+                mo[i][c] = *reinterpret_cast<const float4 *>(rec + 2 * kMaxGroupQ + hg * 128 + d);
+            }
+        }
+    }
     v4u st = {0u, 0u, 0u, 0u};
     if (LN) st = *reinterpret_cast<const v4u *>(p.stats_in + 2 * (size_t)(tid < p.n_stats ? tid : p.n_stats - 1));
     // the storing thread's row(s); other threads request clamped, valid addresses and drop the values
@@ -204,8 +237,56 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
     BH_QSTAMP(1);
 
     // ---- 3. QAct records (and statistics pairs) -> LDS, once per workgroup ------------------------------------
+    if (!MRG) {
 #pragma unroll
-    for (int i = 0; i < NCP; ++i) *reinterpret_cast<v4u *>(cq + 16 * (tid + NT * i)) = qa[i];
+        for (int i = 0; i < NCP; ++i) *reinterpret_cast<v4u *>(cq + 16 * (tid + NT * i)) = qa[i];
+    } else {
+        const int m_chunks = (*p.attn_pos + 64) >> 6;  // live records, 1..4 (the caller switches to the combine kernel beyond that)
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = 4 * (tid + NT * i);
+            // softmax merge: out = sum_c e^(m_c - M) o_c / sum_c e^(m_c - M) l_c   (k_attn_combine's value)
+            float M = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mml[i][c].x = c < m_chunks ? mml[i][c].x : -INFINITY;
+                M = fmaxf(M, mml[i][c].x);
+            }
+            float L = 0.0f;
+            float4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float w = __expf(mml[i][c].x - M);
+                L += w * mml[i][c].y;
+                a.x += w * mo[i][c].x, a.y += w * mo[i][c].y, a.z += w * mo[i][c].z, a.w += w * mo[i][c].w;
+            }
+            const float rl = e < p.cols ? 1.0f / L : 0.0f;
+            const float v[4] = {a.x * rl, a.y * rl, a.z * rl, a.w * rl};
+            // qact_emit's arithmetic (qact.hpp) with the 16-element group spread over 4 lanes x 4 elements; destination = the
+            // LDS image instead of a global record
+            uint32_t u = __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))), o;
+            o = qdpp_u<0xB1>(u), u = o > u ? o : u;  // quad_perm [1,0,3,2]
+            o = qdpp_u<0x4E>(u), u = o > u ? o : u;  // quad_perm [2,3,0,1]: the maximum over the quad = the 16 elements
+            int be = (int)(u >> 23);
+            be = be < 32 ? 32 : be;
+            be = be > 254 ? 254 : be;
+            const float sc = __uint_as_float((uint32_t)(267 - be) << 23), as = __uint_as_float((uint32_t)(be - 13) << 23);
+            uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = ((uint32_t)qcvt_rpi(v[j] * sc) + 0x80u) ^ 0x80u;
+                d0 |= (t & 0xffu) << (8 * j);
+                d1 |= ((t >> 8) & 0xffu) << (8 * j);
+            }
+            if (e < p.cols) {
+                const int grp = e >> 4, rec = grp >> 4, tp = grp & 15;
+                uint8_t *qb = cq + kQRec * rec;
+                *reinterpret_cast<uint32_t *>(qb + 16 * tp + (e & 15)) = d0;
+                *reinterpret_cast<uint32_t *>(qb + 256 + 16 * tp + (e & 15)) = d1;
+                if ((e & 15) == 0) reinterpret_cast<float *>(qb + 512)[4 * (tp >> 2) + 2 * (tp & 1) + ((tp & 3) >> 1)] = as;
+            }
+        }
+    }
     if (LN) *reinterpret_cast<v4u *>(cs + 16 * tid) = st;
     // raw barrier: __syncthreads() would also wait for the weight loads in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -379,7 +460,7 @@ hipError_t launch_embed_q(const void *table, const int *tokens, const int *offse
 }
 
 hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream) {
-    if (!w.tiles || !gemvq_supported(w)) return hipErrorInvalidValue;
+    if (!w.tiles || !gemvq_supported(w) || (!io.qin && !io.attn_rec)) return hipErrorInvalidValue;
     const bool sc_any = w.scaled;
     const int sc = !sc_any ? 0 : w.scales_f16 ? 2 : 1;
     if (sc == 2 && !w.scale_tiles_h) return hipErrorInvalidValue;
@@ -414,6 +495,10 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
     a.qout = static_cast<uint8_t *>(io.qout);
     a.gamma_out = io.gamma_out;
     a.stats_out = io.stats_out;
+    a.attn_rec = io.attn_rec;
+    a.attn_pos = io.attn_pos;
+    a.attn_chunks_max = io.attn_chunks_max;
+    a.attn_group_log2 = io.attn_group_log2;
     a.stamps = g_mfma_stamps;
     if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
     const int tiles_per_wg = nw / ksplit;
@@ -439,6 +524,15 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
                  : (sc == 2 ? k_gemv_q<16, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<16, RINGv, 1, 0, NCPv> : k_gemv_q<16, RINGv, 0, 0, NCPv>);
     BH_QPICK16(2, 1) BH_QPICK16(2, 2) BH_QPICK16(3, 1) BH_QPICK16(3, 2) BH_QPICK16(4, 1) BH_QPICK16(4, 2)
 #undef BH_QPICK16
+    if (io.attn_rec) {  // merging form: the o-projection shape (K = heads * 128 <= 4096: 8 elements per thread at most, ring <= 2)
+        const int ne = (int)div_ceil(w.cols / 4, (size_t)512);  // 4-element slots per thread
+        if (ln || nw != 8 || ring > 2 || ncp != 1 || w.cols % 128 != 0 || ne > 2 || !io.attn_pos || io.attn_chunks_max < 1) return hipErrorInvalidValue;
+#define BH_QMRG(NEv)                                                                                                                   \
+    if (ne <= NEv && !kfn) kfn = sc == 2 ? k_gemv_q<8, 2, 2, 0, 1, NEv> : sc == 1 ? k_gemv_q<8, 2, 1, 0, 1, NEv> : k_gemv_q<8, 2, 0, 0, 1, NEv>;
+        kfn = nullptr;
+        BH_QMRG(1) BH_QMRG(2)
+#undef BH_QMRG
+    }
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;
     const size_t lds = (size_t)ring_t * kQRec + (size_t)ncp * 16 * nw * 64 + (ln ? (size_t)nw * 64 * 16 : 0) + (size_t)nw * 16 * sizeof(float);

@@ -266,3 +266,48 @@ def test_gemv_q_argument_errors(hip, pkg, torch_):
     with pytest.raises(pkg.BitNetHipError, match="multiple of 16"):
         hip.quantize_act_dev(g, None, 100, torch_.zeros(1024, dtype=torch_.uint8, device="cuda"))
     hip.weights_free(h)
+
+
+@pytest.mark.parametrize("n_heads,n_kv,fmt", [(8, 2, "qk256"), (4, 2, "qk256"), (20, 5, "f16"), (3, 3, "qk256")])
+def test_merging_oproj_on_qact_path_equals_combine_then_project(hip, pkg, oracle, torch_, n_heads, n_kv, fmt):
+    """Short contexts: bitnet_hip_attention_decode_partial_dev + bitnet_hip_gemv_attn_merge_q_dev (k_gemv_q merging the chunk
+    records into its LDS image itself) against bitnet_hip_attention_decode_q_dev (combine kernel -> QAct) +
+    bitnet_hip_gemv_q_dev, contexts of 1..4 chunks: same y, same QAct handed to the next GEMV."""
+    D, max_pos = 128, 512
+    cols, rows = n_heads * D, 640
+    rng = np.random.default_rng(11 * n_heads + n_kv)
+    if fmt == "qk256":
+        w = hip.weights_upload_qk256(rng.integers(0, 256, rows * cols // 4, dtype=np.uint8), rows, cols, cols // 4) if cols % 256 == 0 else None
+    else:
+        codes = rng.integers(0, 256, rows * cols // 4, dtype=np.uint8)
+        sc = rng.uniform(0.05, 1.0, rows * cols // 32).astype(np.float16).astype(np.float32)
+        w = hip.weights_upload_i2s(codes, sc, rows, cols, 32)
+    if w is None or not hip.gemv_q_supported(w):
+        pytest.skip("shape not on the QAct path (K % 256 != 0)")
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    sin_d, cos_d = dev(torch_, sin), dev(torch_, cos)
+    sb = hip.c.bitnet_hip_attention_scratch_bytes(n_kv, max_pos)
+    gam = dev(torch_, rng.uniform(0.5, 1.5, rows).astype(np.float32))
+    z = lambda n, dt=torch_.uint8: torch_.zeros(n, dtype=dt, device="cuda")
+    for pos in (0, 1, 63, 64, 130, 255):
+        kc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
+        vc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
+        qkv = dev(torch_, rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32))
+        res = dev(torch_, rng.normal(0, 1, rows).astype(np.float32))
+        pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
+        k1, v1, s1 = dev(torch_, kc), dev(torch_, vc), torch_.zeros(sb // 4 + 16, device="cuda")
+        qa, y1, q1, st1 = z(hip.qact_bytes(cols)), z(rows, torch_.float32), z(hip.qact_bytes(rows)), z(rows // 16 * 2, torch_.float64)
+        hip.attention_decode_q_dev(qkv, sin_d, cos_d, k1, v1, n_heads, n_kv, D, max_pos, pos_d, s1, None, qa)
+        hip.gemv_q_dev(w, qa, y=y1, residual=res, qact_out=q1, gamma_out=gam, stats_out=st1)
+        k2, v2, s2 = dev(torch_, kc), dev(torch_, vc), torch_.zeros(sb // 4 + 16, device="cuda") + 3.0  # stale-but-finite records past the context
+        y2, q2, st2 = z(rows, torch_.float32), z(hip.qact_bytes(rows)), z(rows // 16 * 2, torch_.float64)
+        hip.attention_decode_partial_dev(qkv, sin_d, cos_d, k2, v2, n_heads, n_kv, D, max_pos, pos_d, s2)
+        hip.gemv_attn_merge_q_dev(w, s2, n_heads, n_kv, max_pos, pos_d, y2, q2, residual=res, gamma_out=gam, stats_out=st2)
+        torch_.cuda.synchronize()
+        a, b = y1.cpu().numpy(), y2.cpu().numpy()
+        assert np.max(np.abs(a - b)) <= 3e-5 * max(1.0, np.max(np.abs(a))), (n_heads, n_kv, pos, np.max(np.abs(a - b)))
+        da, db = dequantize_qact(q1.cpu().numpy(), rows), dequantize_qact(q2.cpu().numpy(), rows)
+        assert np.max(np.abs(da - db)) <= 2e-4 * max(1.0, np.max(np.abs(da)))
+        assert np.array_equal(q2.cpu().numpy(), quantize_qact(b, gam.cpu().numpy()))  # its own output, quantised exactly as specified
+        assert torch_.equal(k1, k2) and torch_.equal(v1, v2)
+    hip.weights_free(w)
