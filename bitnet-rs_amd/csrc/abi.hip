@@ -37,6 +37,7 @@ void free_weights(Weights *w) {
     if (w->codes) (void)hipFree(w->codes);
     if (w->scales) (void)hipFree(w->scales);
     if (w->tiles) (void)hipFree(w->tiles);
+    if (w->tiles_k32) (void)hipFree(w->tiles_k32);
     if (w->scale_tiles) (void)hipFree(w->scale_tiles);
     if (w->scale_tiles_h) (void)hipFree(w->scale_tiles_h);
     if (w->ln_g) (void)hipFree(w->ln_g);
@@ -412,7 +413,7 @@ static int matmul_dev_kernel(bitnet_hip_weights_t h, const float *x_dev, float *
         // released IN STREAM ORDER (no host synchronisation, nothing that outlives the call on the host side);
         // callers that replay the call from a hipGraph pass their own workspace to bitnet_hip_matmul_fused_dev.
         const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
-        if (w->scaled && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
+        if (gemm_needs_row_major_scales(*w) && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
             return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
         void *ws = nullptr;
         if (hipMallocAsync(&ws, wsb, (hipStream_t)stream) != hipSuccess)
@@ -461,7 +462,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     const size_t need = gemm_workspace_bytes(m, w->cols, digits);
     if (!workspace_dev || workspace_bytes < need)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_dev ? workspace_bytes : (size_t)0);
-    if (w->scaled && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)  // the tiled matmul reads row-major block scales
+    if (gemm_needs_row_major_scales(*w) && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
         return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
@@ -531,6 +532,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->codes = nullptr;
     f->scales = nullptr;
     f->tiles = nullptr;
+    f->tiles_k32 = nullptr;
     f->scale_tiles = nullptr;
     f->scale_tiles_h = nullptr;
     f->ln_g = nullptr;

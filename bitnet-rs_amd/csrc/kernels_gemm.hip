@@ -21,6 +21,7 @@
 //                  tiles are the GEMV's 1-KiB lane-ordered tiles, straight into registers.
 // Weights are read once per 32*TTW tokens (2 bits each: cheap); the int8 activation tile is
 // the larger stream and is shared by the 4 row-waves through LDS.
+#include <mutex>
 #include <unordered_set>
 
 #include "common.hpp"
@@ -40,7 +41,8 @@ struct GemmArgs {
     float *y;                // [m, rows] ([m, rows/2] with silu_mul)
     int m;
     const float *residual;  // optional [m, rows]
-    const float *wscale;    // optional f32 per (row, 256-block)
+    const float *wscale;    // optional f32 per (row, 256-block) / (row, 32-block), row-major
+    const uint16_t *stiles_h;  // WS == 3: f16 32-block scale tiles [tile][blk][kg][row][p] (k_retile_scales_h)
     int silu_mul;
 };
 
@@ -164,6 +166,25 @@ __device__ __forceinline__ v4i gdecode16(uint32_t w, uint32_t lut) {
     return a;
 }
 
+// the same value from ONE conversion where the integer fits (a 32-block's digit sums are < 2^14 each): exact integer
+// d0 + 256 d1 (+ 65536 d2), rounded once by the conversion -- what the f32 additions of exact terms give too
+template <int NDIG>
+__device__ __forceinline__ float combine_digits_i(const v4i *acc, int j) {
+    if (NDIG == 2) return (float)(int)(((uint32_t)acc[1][j] << 8) + (uint32_t)acc[0][j]);
+    if (NDIG == 3) return (float)(int)(((((uint32_t)acc[2][j] << 8) + (uint32_t)acc[1][j]) << 8) + (uint32_t)acc[0][j]);
+    return (float)(int)(((uint32_t)acc[1][j] << 8) + (uint32_t)acc[0][j]) + (65536.0f * (float)acc[2][j] + 16777216.0f * (float)acc[3][j]);
+}
+__device__ __forceinline__ float gfma_mix_lo(float a, uint32_t h, float c) {  // a * f16(h[15:0]) + c
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float gfma_mix_hi(float a, uint32_t h, float c) {  // a * f16(h[31:16]) + c
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(h), "v"(c));
+    return r;
+}
+
 template <int NDIG>
 __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
     // ((d0 + 256 d1) + (65536 d2 + 2^24 d3)): the GEMV's order
@@ -175,6 +196,10 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
 // WS: 0 no weight scales; 1 one f32 scale per (row, 256-block); 2 one per (row, 32-block): the four
 // lane groups of an MFMA's K = 64 belong to four different 32-blocks, so B is masked to one lane group at a
 // time (4x the MFMAs) and every pair of MFMAs is folded into f32 with its block's scale.
+// WS == 3: 32-block scales on v_mfma_i32_16x16x32_i8 -- one MFMA = one 32-weight block, no masking (the K = 64 form has four
+// different blocks in its four lane groups: WS == 2 masks B to one lane group at a time, 4x the MFMAs).  Needs the tiles dealt for
+// K = 32 (Weights::tiles_k32: lane group g holds columns 8 g .. 8 g + 7 of every 32-block; dword i of a lane = blocks 2 i and
+// 2 i + 1, so the GEMV's 16-code decode yields both blocks' 8-byte A operands) and reads its scales as f16 tiles.
 template <int NDIG, int TTW, int WS>
 __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
@@ -261,6 +286,19 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
         }
     }
 
+    // K = 32 form: this lane's f16 scale tiles, one 16-byte load per (row tile, 64 columns)
+    const uint16_t *sptr[WS == 3 ? 4 : 1];
+    uint4 scn[WS == 3 ? 4 : 1];
+    if (WS == 3) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            int t = bx * 16 + rw * 4 + rt;
+            t = t < n_tiles ? t : n_tiles - 1;
+            sptr[rt] = p.stiles_h + (size_t)t * p.nblk * 128 + 8 * g;
+            scn[rt] = *reinterpret_cast<const uint4 *>(sptr[rt]);
+        }
+    }
+
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = bread;
         if (WS) {  // scaled variant: registers go to the f32 accumulators: single buffer, no prefetch
@@ -292,7 +330,55 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n2 * 256);
         }
-        if (WS != 2) {
+        if (WS == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // dword i of the lane = 32-blocks 2 i, 2 i + 1 of this 256-block
+                // scales of step (blk, i): 16 bytes per row tile = rows 4 g .. 4 g + 3 x (block 2 i, 2 i + 1); the next step's
+                // are requested now and used one iteration later
+                uint4 scc[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) scc[rt] = scn[rt];
+                {
+                    int nx = blk * 4 + i + 1;
+                    nx = nx < p.nblk * 4 ? nx : p.nblk * 4 - 1;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) scn[rt] = *reinterpret_cast<const uint4 *>(sptr[rt] + 32 * nx);
+                }
+                v4i a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const uint32_t wd = i == 0 ? wc[rt].x : i == 1 ? wc[rt].y : i == 2 ? wc[rt].z : wc[rt].w;
+                    a[rt] = gdecode16(wd, p.lut);
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    // one MFMA = one 32-block: results start from the inline constant 0 (nothing to clear afterwards)
+                    const v4i zero = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        // bread points at column byte 64 g: this lane's eight k of 32-block 2 i + hb sit at 32 (2 i + hb) + 8 g
+                        const long b = *reinterpret_cast<const long *>(bcur + ct * 16 * kColStride + 64 * i + 32 * hb - 56 * g);
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) {
+                            const long av = (long)(uint32_t)a[rt][2 * hb] | ((long)(uint32_t)a[rt][2 * hb + 1] << 32);
+                            acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, b, zero, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        const uint32_t sw[4] = {scc[rt].x, scc[rt].y, scc[rt].z, scc[rt].w};  // dword j = row 4 g + j: (block 2 i, 2 i + 1)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int tt = 0; tt < TTW; ++tt) {
+                                const float cv = combine_digits_i<NDIG>(&acc[rt][tt * NDIG], j);
+                                facc[rt][tt][j] = hb ? gfma_mix_hi(cv, sw[j], facc[rt][tt][j]) : gfma_mix_lo(cv, sw[j], facc[rt][tt][j]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (WS != 2) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 v4i a[4];
@@ -414,8 +500,56 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
     }
 }
 
+// ---- tiles re-dealt for K = 32 MFMAs: out lane (r, g) dword i element e <- column 32 (2 i + (e >> 3)) + 8 g + (e & 7) of the block ----
+__device__ __forceinline__ uint32_t transpose_fields_g(uint32_t w) {  // 4 x 4 transpose of the sixteen 2-bit fields (an involution)
+    uint32_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o |= ((w >> (2 * (4 * i + b))) & 3u) << (2 * (4 * b + i));
+    return o;
+}
+__global__ void k_retile_k32(const uint32_t *__restrict__ tiles, uint32_t *__restrict__ out, size_t total_dwords) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one output dword
+    if (id >= total_dwords) return;
+    const int i = (int)(id & 3), lane = (int)((id >> 2) & 63), r = lane & 15, g = lane >> 4;
+    const size_t tb = id >> 8;  // (tile, block): 256 dwords each
+    uint32_t w = 0;
+    for (int e = 0; e < 16; ++e) {
+        const int k = 32 * (2 * i + (e >> 3)) + 8 * g + (e & 7);               // column inside the 256-block
+        const int gs = k >> 6, ms = (k >> 4) & 3, es = k & 15;                   // source lane group, dword, element
+        const uint32_t src = transpose_fields_g(tiles[tb * 256 + (size_t)(16 * gs + r) * 4 + ms]);  // natural field order
+        w |= ((src >> (2 * es)) & 3u) << (2 * e);
+    }
+    out[id] = transpose_fields_g(w);
+}
+static std::mutex g_k32_mu;
+static hipError_t ensure_tiles_k32(const Weights &cw, hipStream_t stream) {
+    Weights &w = const_cast<Weights &>(cw);  // a lazily built cache of the same matrix
+    std::lock_guard<std::mutex> lk(g_k32_mu);
+    if (w.tiles_k32) return hipSuccess;
+    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256), total = n_tiles * nblk * 256;
+    uint8_t *buf = nullptr;
+    hipError_t e = hipMalloc((void **)&buf, total * 4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_retile_k32, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(w.tiles),
+                       reinterpret_cast<uint32_t *>(buf), total);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return e;
+    }
+    w.tiles_k32 = buf;
+    return hipSuccess;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
-static int gemm_ttw(int ndig, int ws) { return ws == 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
+static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
+
+// 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
+static bool gemm_k32(const Weights &w) { return w.scaled && w.block_size == 32 && w.scales_f16 && w.scale_tiles_h && w.cols % 256 == 0; }
+bool gemm_needs_row_major_scales(const Weights &w) { return w.scaled && !gemm_k32(w); }
 
 bool gemm_supported(const Weights &w) {
     if (!w.tiles || w.cols % 4 != 0 || w.cols > 8192) return false;
@@ -436,11 +570,13 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<NDIG, 3> : k_quant_rows<NDIG, 8>;
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
-    const bool bs32 = a.wscale && w.block_size == 32;  // 32-block scales: one token tile per wave (registers)
+    const bool k32 = a.stiles_h != nullptr;
+    const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
     constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
-    void (*gk)(GemmArgs) = !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    const int ttw = !a.wscale ? TTW : bs32 ? TT32 : TTWS;
-    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (a.wscale ? 1 : 2);  // unscaled variant: double-buffered
+    void (*gk)(GemmArgs) = k32 ? k_gemm_mfma<NDIG, TT32, 3> : !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
+    const int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS;
+    const bool scaled_variant = a.wscale || k32;
+    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2);  // unscaled variant: double-buffered
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -456,8 +592,13 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
                             void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
     if (workspace_bytes < gemm_workspace_bytes(m, w.cols, ndig) || !workspace) return hipErrorInvalidValue;
+    const bool k32 = gemm_k32(w);
     const int ws_mode = !w.scaled ? 0 : w.block_size == 32 ? 2 : 1;
-    if (w.scaled && !w.scales) return hipErrorInvalidValue;  // the caller materialises the row-major scales (ensure_reference)
+    if (gemm_needs_row_major_scales(w) && !w.scales) return hipErrorInvalidValue;  // the caller materialises them (ensure_reference)
+    if (k32) {
+        const hipError_t e = ensure_tiles_k32(w, stream);
+        if (e != hipSuccess) return e;
+    }
     const size_t wg_tokens = (size_t)32 * gemm_ttw(ndig, ws_mode), m_pad = div_ceil(m, wg_tokens) * wg_tokens;
     QuantArgs q;
     q.x = x;
@@ -472,7 +613,8 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     q.inv_scale = reinterpret_cast<float *>(ws);
     q.planes = reinterpret_cast<int8_t *>(ws + div_ceil(m_pad * 4, 256) * 256);
     GemmArgs a;
-    a.tiles = w.tiles;
+    a.tiles = k32 ? w.tiles_k32 : w.tiles;
+    a.stiles_h = k32 ? w.scale_tiles_h : nullptr;
     a.rows = (int)w.rows;
     a.cols = (int)w.cols;
     a.nblk = (int)div_ceil(w.cols, 256);
@@ -482,7 +624,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.y = y;
     a.m = (int)m;
     a.residual = fu.residual;
-    a.wscale = w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
+    a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);

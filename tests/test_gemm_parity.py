@@ -114,21 +114,26 @@ def test_gemm_fusions_ln_residual_silu(hip, oracle, torch_):
         hip.weights_free(h)
 
 
-@pytest.mark.parametrize("block", [256, 32])
-def test_ternary_scaled_gemm(hip, oracle, torch_, block):
-    """i2s_matmul_f32 semantics with m rows: 256-element scales run in the tiled kernel, 32-element
-    block scales fall back to the per-row GEMV inside the same entry point."""
-    rng = np.random.default_rng(block)
-    n, k, m = 384, 1024, 40
+@pytest.mark.parametrize("block,f16_scales,n,k,m", [(256, False, 384, 1024, 40), (32, False, 384, 1024, 40), (32, True, 384, 1024, 40),
+                                                     (32, True, 1000, 2560, 70), (32, True, 48, 256, 1)])
+def test_ternary_scaled_gemm(hip, oracle, torch_, block, f16_scales, n, k, m):
+    """i2s_matmul_f32 semantics with m rows.  256-element scales fold once per 256-block; 32-element scales that are f16
+    values (what a GGUF I2_S file holds) run on the K = 32 MFMA with f16 scale tiles, other 32-element scales on the masked
+    K = 64 form with row-major f32 scales."""
+    rng = np.random.default_rng(block + n)
     codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(n, k), p=[0.5, 0.25, 0.25])
     packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
     scales = (1.0 / ((np.arange(n * (k // block)) % 100) + 1)).astype(np.float32)
+    if f16_scales:
+        scales = scales.astype(np.float16).astype(np.float32)
     x = rng.uniform(-4, 4, (m, k)).astype(np.float32)
     want = oracle.i2s_matmul(x.reshape(-1), packed.reshape(-1), scales, m, n, k, block).reshape(m, n)
     h = hip.weights_upload_i2s(packed.reshape(-1), scales, n, k, block)
     for digits in (4, 3):
         got = run_gemm(hip, torch_, h, x, n, digits)
         assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)) + 1e-6, (block, digits)
+    got = run_gemm(hip, torch_, h, x, n, 2)  # 16-bit activations: 2^-15 of each row's maximum per element
+    assert np.max(np.abs(got - want)) <= 2e-4 * np.max(np.abs(want)) + 1e-6, (block, 2)
     hip.weights_free(h)
 
 
