@@ -200,8 +200,12 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
 // different blocks in its four lane groups: WS == 2 masks B to one lane group at a time, 4x the MFMAs).  Needs the tiles dealt for
 // K = 32 (Weights::tiles_k32: lane group g holds columns 8 g .. 8 g + 7 of every 32-block; dword i of a lane = blocks 2 i and
 // 2 i + 1, so the GEMV's 16-code decode yields both blocks' 8-byte A operands) and reads its scales as f16 tiles.
-template <int NDIG, int TTW, int WS>
-__global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
+// MINW = 4 waves per SIMD = two workgroups per CU (<= 128 registers): the narrow-token-tile form for launches whose wide-tile grid would
+// leave most CUs idle in its last round (a 2560-row matrix x 4096 tokens = 320 wide workgroups on 256 CUs).
+typedef unsigned gv4u __attribute__((ext_vector_type(4)));
+
+template <int NDIG, int TTW, int WS, int MINW = 1>
+__global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
     constexpr int WG_COLS = 2 * CT * 16;    // plane rows per workgroup
     constexpr int NB = WG_COLS * 16 / 512;  // uint4 per thread per K step
@@ -241,18 +245,18 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
         bdst[i] = col * kColStride + seg * 16;
     }
     constexpr int kBuf = WG_COLS * kColStride;  // one activation tile in LDS; the unscaled variant keeps two
-    uint4 wn[4], bn[NB];
+    gv4u wn[4], bn[NB];  // native vectors: arrays of HIP's uint4 struct are kept in scratch memory by this compiler
     if (!WS) {
         // prologue: activation tile 0 -> LDS buffer 0, tile 1's loads in flight; weights of step 0 in flight
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt]);
+        for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i]);
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
         const int n1 = p.nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n1 * 256);
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 256);
         __syncthreads();
     }
     v4i acc[4][CT];
@@ -288,14 +292,14 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
 
     // K = 32 form: this lane's f16 scale tiles, one 16-byte load per (row tile, 64 columns)
     const uint16_t *sptr[WS == 3 ? 4 : 1];
-    uint4 scn[WS == 3 ? 4 : 1];
+    gv4u scn[WS == 3 ? 4 : 1];
     if (WS == 3) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             int t = bx * 16 + rw * 4 + rt;
             t = t < n_tiles ? t : n_tiles - 1;
             sptr[rt] = p.stiles_h + (size_t)t * p.nblk * 128 + 8 * g;
-            scn[rt] = *reinterpret_cast<const uint4 *>(sptr[rt]);
+            scn[rt] = *reinterpret_cast<const gv4u *>(sptr[rt]);
         }
     }
 
@@ -303,12 +307,12 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
         const uint8_t *bcur = bread;
         if (WS) {  // scaled variant: registers go to the f32 accumulators: single buffer, no prefetch
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)blk * 1024);
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)blk * 1024);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)blk * 256);
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)blk * 256);
             __syncthreads();  // the previous step's LDS reads are done
 #pragma unroll
-            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(lds + bdst[i]) = bn[i];
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
             __syncthreads();
         } else {
             // tile blk is in buffer blk & 1 (everyone passed the barrier that ended step blk - 1, so nobody still
@@ -317,32 +321,32 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(GemmArgs p) {
             uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
             if (blk + 1 < p.nblk) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4 *>(nxt + bdst[i]) = bn[i];
+                for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
             }
         }
-        uint4 wc[4];
+        gv4u wc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) wc[rt] = wn[rt];
         if (!WS) {
             const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const uint4 *>(wptr[rt] + (size_t)n1 * 1024);  // next step's weights
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);  // next step's weights
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const uint4 *>(bsrc[i] + (size_t)n2 * 256);
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 256);
         }
         if (WS == 3) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // dword i of the lane = 32-blocks 2 i, 2 i + 1 of this 256-block
                 // scales of step (blk, i): 16 bytes per row tile = rows 4 g .. 4 g + 3 x (block 2 i, 2 i + 1); the next step's
                 // are requested now and used one iteration later
-                uint4 scc[4];
+                gv4u scc[4];
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) scc[rt] = scn[rt];
                 {
                     int nx = blk * 4 + i + 1;
                     nx = nx < p.nblk * 4 ? nx : p.nblk * 4 - 1;
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) scn[rt] = *reinterpret_cast<const uint4 *>(sptr[rt] + 32 * nx);
+                    for (int rt = 0; rt < 4; ++rt) scn[rt] = *reinterpret_cast<const gv4u *>(sptr[rt] + 32 * nx);
                 }
                 v4i a[4];
 #pragma unroll
@@ -545,6 +549,7 @@ static hipError_t ensure_tiles_k32(const Weights &cw, hipStream_t stream) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
+constexpr size_t kGemmCUs = 256;
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -574,8 +579,17 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
     constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
     void (*gk)(GemmArgs) = k32 ? k_gemm_mfma<NDIG, TT32, 3> : !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    const int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS;
+    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS;
     const bool scaled_variant = a.wscale || k32;
+    if (NDIG == 2 && !scaled_variant) {
+        // wide tiles: 256 rows x 128 tokens, one workgroup per CU.  When the last round of that grid is mostly empty, the
+        // half-width tiles (two resident per CU) spread the same work evenly
+        const size_t wide = div_ceil(div_ceil(w.rows, 16), 16) * (size_t)(q.m_pad / 128), rounds = div_ceil(wide, kGemmCUs);
+        if ((double)wide / (double)(rounds * kGemmCUs) < 0.8) {
+            gk = k_gemm_mfma<2, 2, 0, 4>;
+            ttw = 2;
+        }
+    }
     const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2);  // unscaled variant: double-buffered
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
