@@ -33,17 +33,23 @@ __device__ __forceinline__ void transpose4x4(uint32_t r0, uint32_t r1, uint32_t 
     c3 = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
-// grid (ceil(n / 4 / 256), ceil(m / kMR)); requires n % 4 == 0, k % 4 == 0, 4-byte aligned a rows (k % 4 == 0) and b
-__global__ __launch_bounds__(256) void k_matmul_i2s_tiled(const int8_t *__restrict__ a, const uint8_t *__restrict__ b, float *__restrict__ c, int m,
-                                                          int n, int k) {
-    const int j4 = blockIdx.x * 256 + threadIdx.x;  // column group
+// grid (ceil(n / 4 / 64), ceil(m / kMR), K parts); requires n % 4 == 0, k % 4 == 0, 4-byte aligned a rows (k % 4 == 0) and b.
+// One thread = 4 adjacent output columns x kMR rows over one K part [z kc, z kc + kc): with a single K part it stores f32,
+// otherwise it adds its exact int32 partial sums into c (zeroed beforehand, read as int32) and k_i32_to_f32 converts in
+// place -- integer addition commutes, so the result does not depend on the order the parts arrive in.  (One K part only
+// would leave a 1 x 2560 x 2560 product on 10 waves.)
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void k_matmul_i2s_tiled(const int8_t *__restrict__ a, const uint8_t *__restrict__ b, float *__restrict__ c, int m,
+                                                         int n, int k, int kc) {
+    const int j4 = blockIdx.x * 64 + threadIdx.x;  // column group
     if (4 * j4 >= n) return;
     const int i0 = blockIdx.y * kMR;
+    const int k0 = SPLIT ? blockIdx.z * kc : 0, k1 = SPLIT ? (k0 + kc < k ? k0 + kc : k) : k;
     const uint32_t *b32 = reinterpret_cast<const uint32_t *>(b) + j4;
     const size_t ldb = (size_t)n / 4;
     uint32_t acc[kMR][4] = {};
     uint32_t bs[4] = {0, 0, 0, 0};  // column sums of b
-    for (int l = 0; l < k; l += 4) {
+    for (int l = k0; l < k1; l += 4) {
         const uint32_t r0 = b32[(size_t)l * ldb], r1 = b32[(size_t)(l + 1) * ldb], r2 = b32[(size_t)(l + 2) * ldb], r3 = b32[(size_t)(l + 3) * ldb];
         uint32_t col[4];
         transpose4x4(r0, r1, r2, r3, col[0], col[1], col[2], col[3]);
@@ -60,13 +66,23 @@ __global__ __launch_bounds__(256) void k_matmul_i2s_tiled(const int8_t *__restri
 #pragma unroll
     for (int i = 0; i < kMR; ++i) {
         if (i0 + i >= m) break;
-        float4 o;
-        o.x = (float)(int32_t)(acc[i][0] - 128u * bs[0]);
-        o.y = (float)(int32_t)(acc[i][1] - 128u * bs[1]);
-        o.z = (float)(int32_t)(acc[i][2] - 128u * bs[2]);
-        o.w = (float)(int32_t)(acc[i][3] - 128u * bs[3]);
-        *reinterpret_cast<float4 *>(c + (size_t)(i0 + i) * n + 4 * j4) = o;
+        float *dst = c + (size_t)(i0 + i) * n + 4 * j4;
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(reinterpret_cast<int *>(dst) + j, (int)(acc[i][j] - 128u * bs[j]));
+        } else {
+            float4 o;
+            o.x = (float)(int32_t)(acc[i][0] - 128u * bs[0]);
+            o.y = (float)(int32_t)(acc[i][1] - 128u * bs[1]);
+            o.z = (float)(int32_t)(acc[i][2] - 128u * bs[2]);
+            o.w = (float)(int32_t)(acc[i][3] - 128u * bs[3]);
+            *reinterpret_cast<float4 *>(dst) = o;
+        }
     }
+}
+__global__ void k_i32_to_f32(float *__restrict__ c, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) c[i] = (float)reinterpret_cast<const int *>(c)[i];
 }
 
 // quantize_input_i2s (quantized_linear.rs:1762-1773): clamp(x, -2, 1).round() as i8 -- f32::round is half away from zero,
@@ -132,8 +148,20 @@ __global__ __launch_bounds__(256) void k_quantize_i2s_fast(const float *__restri
 hipError_t launch_matmul_i2s_tiled(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n, size_t k, hipStream_t stream) {
     if (m == 0 || n == 0) return hipSuccess;
     if (n % 4 != 0 || k % 4 != 0 || k == 0 || k > 65536 || ((uintptr_t)a & 3) || ((uintptr_t)b & 3) || ((uintptr_t)c & 15)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_matmul_i2s_tiled, dim3((unsigned)div_ceil(n / 4, 256), (unsigned)div_ceil(m, kMR)), dim3(256), 0, stream, a, b, c, (int)m, (int)n,
-                       (int)k);
+    const size_t gx = div_ceil(n / 4, 64), gy = div_ceil(m, kMR);
+    // enough K parts for ~4 waves per SIMD-quarter of the chip, each at least 64 deep
+    size_t parts = div_ceil((size_t)2048, gx * gy);
+    parts = parts > k / 64 ? k / 64 : parts;
+    if (parts <= 1) {
+        hipLaunchKernelGGL(k_matmul_i2s_tiled<false>, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, stream, a, b, c, (int)m, (int)n, (int)k, (int)k);
+        return hipGetLastError();
+    }
+    const size_t kc = div_ceil(div_ceil(k, parts), 4) * 4;
+    parts = div_ceil(k, kc);
+    hipError_t e = hipMemsetAsync(c, 0, m * n * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_matmul_i2s_tiled<true>, dim3((unsigned)gx, (unsigned)gy, (unsigned)parts), dim3(64), 0, stream, a, b, c, (int)m, (int)n, (int)k, (int)kc);
+    hipLaunchKernelGGL(k_i32_to_f32, dim3((unsigned)div_ceil(m * n, 256)), dim3(256), 0, stream, c, m * n);
     return hipGetLastError();
 }
 bool matmul_i2s_tiled_ok(size_t m, size_t n, size_t k) { return m > 0 && n % 4 == 0 && k % 4 == 0 && k > 0 && k <= 65536; }
