@@ -527,10 +527,9 @@ __global__ void k_retile_k32(const uint32_t *__restrict__ tiles, uint32_t *__res
     }
     out[id] = transpose_fields_g(w);
 }
-static std::mutex g_k32_mu;
 static hipError_t ensure_tiles_k32(const Weights &cw, hipStream_t stream) {
     Weights &w = const_cast<Weights &>(cw);  // a lazily built cache of the same matrix
-    std::lock_guard<std::mutex> lk(g_k32_mu);
+    std::lock_guard<std::mutex> lk(*w.mu);
     if (w.tiles_k32) return hipSuccess;
     const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256), total = n_tiles * nblk * 256;
     uint8_t *buf = nullptr;

@@ -857,6 +857,10 @@ void trim_reference(Weights &w) {
         (void)hipFree(w.scales);
         w.scales = nullptr;
     }
+    if (w.tiles_k32) {  // the tiled matmul's K = 32 deal of the same codes (kernels_gemm.hip rebuilds it on its next use)
+        (void)hipFree(w.tiles_k32);
+        w.tiles_k32 = nullptr;
+    }
 }
 
 hipError_t ensure_reference(Weights &w, hipStream_t stream) {
