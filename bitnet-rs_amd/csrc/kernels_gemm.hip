@@ -319,7 +319,11 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
             // reads the other buffer): stage tile blk + 1 there now, then start the loads of tile blk + 2
             bcur = bread + (blk & 1) * kBuf;
             uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
+#if defined(BH_ABLATE) && (BH_ABLATE & 4)  // developer build: no LDS staging stores
+            if (blk + 1 < p.nblk && p.m < 0) {
+#else
             if (blk + 1 < p.nblk) {
+#endif
 #pragma unroll
                 for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
             }
@@ -329,10 +333,14 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
         for (int rt = 0; rt < 4; ++rt) wc[rt] = wn[rt];
         if (!WS) {
             const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
+#if !(defined(BH_ABLATE) && (BH_ABLATE & 32))  // developer build: no weight loads in the loop
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);  // next step's weights
+#endif
+#if !(defined(BH_ABLATE) && (BH_ABLATE & 8))  // developer build: no activation tile loads
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 256);
+#endif
         }
         if (WS == 3) {
 #pragma unroll
@@ -389,11 +397,19 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
+#if defined(BH_ABLATE) && (BH_ABLATE & 2)  // developer build: no code expansion
+                    a[rt] = (v4i){(int)wd, (int)(wd >> 1), (int)(wd >> 2), (int)(wd >> 3)};
+#else
                     a[rt] = gdecode16(wd, p.lut);
+#endif
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+#if defined(BH_ABLATE) && (BH_ABLATE & 1)  // developer build: no LDS operand reads
+                    const v4i b = (v4i){ct + blk, m, ct, 1};
+#else
                     const v4i b = *reinterpret_cast<const v4i *>(bcur + ct * 16 * kColStride + 16 * m);
+#endif
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], b, acc[rt][ct], 0, 0, 0);
                 }
@@ -437,7 +453,9 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
                 }
             }
         }
+#if !(defined(BH_ABLATE) && (BH_ABLATE & 16))  // developer build: no barrier per K step
         if (!WS) __syncthreads();  // every wave is done with buffer blk & 1
+#endif
         if (WS == 1) {
             // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
 #pragma unroll
