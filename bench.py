@@ -194,6 +194,8 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
     comm, gather, how = None, None, "none (1 GPU)"
     if r.world > 1:
         if r.backend == "nccl":
+            import torch.distributed as dist
+
             try:
                 rccl = importlib.import_module("bitnet-rs_amd.rccl")
                 comm = rccl.Comm(r.rank, r.world)
@@ -201,6 +203,12 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
             except Exception as e:  # noqa: BLE001 -- a second communicator could not be created: torch's own carries the gather
                 comm = None
                 sys.stderr.write(f"rank {r.rank}: own RCCL communicator failed ({e!r}); using torch.distributed's\n")
+            # every rank must take the same route (a rank on the fallback while the others call ncclAllGather would deadlock)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         if comm is None:
             gather = tp_mod.torch_gather(r.world)
             how = f"torch.distributed all_gather_into_tensor ({r.backend}, host-synchronised)"
@@ -268,6 +276,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
+    ap.add_argument("--c5-timeout", type=float, default=240.0, help="N > 1: seconds the token-parallel prefill part may take before the line is printed without it")
     ap.add_argument("--gguf", default=None, help="a real model file instead of synthetic weights (default: $BITNET_GGUF if set); the line then says data: gguf")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the token-parallel prefill that normally rides in the same line")
     ap.add_argument("--c5-prompt", type=int, default=8192, help="prompt length of that prefill (a multiple of 128 x N)")
@@ -425,10 +434,34 @@ def main():
     # -- the token-parallel prefill of BASELINE configs[4] -- runs here too, over the same ranks, and rides in the same line
     c5 = None
     if n_gpus > 1 and args.workload in ("c2", "c3") and not args.no_c5:
-        dec.close()
-        cfg5, dec5, _ = build_model(pkg, synth, "c5", args.layers)
-        c5 = sharded_prefill(args, pkg, synth, dist_, r, cfg5, dec5, args.c5_prompt, 2, 1)
-        dec = dec5
+        # The decode numbers above must reach the driver whatever this first multi-GPU execution of the collective does:
+        # every rank arms the same timer; if the prefill has not finished by then, rank 0 prints the line with the reason and
+        # every rank leaves (a rank that waits in a collective for one that failed would otherwise sit there until the
+        # launcher's own limit).
+        import threading
+
+        done = threading.Event()
+
+        def give_up():
+            if done.is_set():
+                return
+            if rank == 0:
+                out["prefill_c5"] = {"error": f"token-parallel prefill did not finish within {args.c5_timeout} s; decode replicas above are unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.c5_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            dec.close()
+            cfg5, dec5, _ = build_model(pkg, synth, "c5", args.layers)
+            dec = dec5
+            c5 = sharded_prefill(args, pkg, synth, dist_, r, cfg5, dec5, args.c5_prompt, 2, 1)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, not swallowed
+            c5 = {"error": f"{type(e).__name__}: {e}"}
+        done.set()
+        timer.cancel()
     if rank == 0:
         if c5 is not None:
             out["prefill_c5"] = c5
