@@ -434,7 +434,7 @@ int Decoder::step_launches(bool with_logits, int form, Tracer *tr) {
     if (qact_path()) {
         // Every vector that travels between two GEMVs goes as a QAct written by its producer's epilogue (x: embedding /
         // down-projection, attention output: combine kernel or merging o-projection, x2: o-projection, h: gate|up).
-        const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
+        const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, MP = (size_t)c_.max_pos;
         BCHK(bitnet_hip_embed_q_dev(embed_, history_, pos_, H, (size_t)c_.vocab, x_, layers_[0].attn_norm, qa_x_, st_x_, s));
         TRACE(tp + "embeddings", "embeddings", -1, x_, H);
         for (size_t l = 0; l < layers_.size(); ++l) {
@@ -928,7 +928,6 @@ int Decoder::probe_kernel(int kind, int reps, float *us_per_launch, double *byte
     for (size_t li = 0; li < layers_.size(); ++li) {
         Layer &L = layers_[li];
         if (qp && kind <= 4) {
-            const size_t NH = (size_t)c_.n_heads, NK = (size_t)c_.n_kv_heads, D = (size_t)c_.head_dim, MP = (size_t)c_.max_pos;
             const bool more = li + 1 < layers_.size();
             switch (kind) {
                 case 0: rc = bitnet_hip_gemv_q_dev(L.qkv, qa_x_, st_x_, L.attn_norm, c_.eps, nullptr, 0, qkv_, nullptr, nullptr, nullptr, stream_); break;
