@@ -33,10 +33,11 @@ class Comm:
         uid = UniqueId()
         if rank == 0:
             self._check(L.ncclGetUniqueId(C.byref(uid)))
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, 0)
-        C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+        if world > 1:  # a single-rank communicator (tests) needs no exchange
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
         self.comm = C.c_void_p()
         self._check(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank))
 

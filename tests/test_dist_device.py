@@ -70,3 +70,32 @@ def test_bench_two_ranks_one_line_with_prefill_c5(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)
+
+
+def test_rccl_single_rank_allgather_through_the_c_entry(pkg, hip):
+    """The RCCL route of the token-parallel prefill with the one rank this box can host: a communicator created as
+    bitnet-rs_amd/rccl.py (and a Rust host) does it, ncclAllGather issued by the C entry bitnet_host_rccl_allgather on a stream
+    of ours -- the dlopen / dlsym resolution, the argument order and the datatype code are what this pins (with one rank the
+    gathered buffer is the send buffer)."""
+    import ctypes as C
+
+    import torch
+
+    rccl = importlib.import_module("bitnet-rs_amd.rccl")
+    comm = rccl.Comm(0, 1)
+    assert comm.handle != 0
+    C.CDLL(pkg.LIB_PATH, mode=C.RTLD_GLOBAL)
+    host = C.CDLL(pkg.HOST_LIB_PATH)
+    host.bitnet_host_rccl_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    host.bitnet_host_rccl_allgather.restype = C.c_int
+    n = 1 << 20
+    send = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+    recv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    rc = host.bitnet_host_rccl_allgather(C.c_void_p(comm.handle), C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n, C.c_void_p(stream.cuda_stream))
+    assert rc == 0
+    stream.synchronize()
+    assert torch.equal(send, recv)
+    assert host.bitnet_host_rccl_allgather(None, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n, None) != 0  # no communicator
+    comm.close()
