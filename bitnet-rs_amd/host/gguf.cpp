@@ -499,7 +499,16 @@ bool make_spec(const GgufFile &g, const GgufTensor &t, size_t rows, size_t cols,
         return false;
     }
     const size_t avail = (size_t)t.size;
-    if (t.shape.size() == 2 && loader_is_qk256(t.shape, avail)) {
+    // llama.cpp writers (the Microsoft 2B file among them: the reference's own tests/gqa_shapes.rs:22 quotes k_proj as
+    // [2560, 640]) label a matrix ne[0] = in first while the bytes are [out rows][in contiguous].  With in = 2560 and
+    // out = 640 the per-row byte count of the LABELLED orientation (2560 rows x 3 blocks) does not match the data, the
+    // reference's second pass (gguf_simple.rs:286-302) therefore does not take the tensor although its first pass skipped
+    // it as QK256 -- it ends up in neither map.  The device path takes it in the orientation the model configuration
+    // names (expected_qk256_shape, qk256_utils.rs:19-55) when THAT orientation's per-row byte count matches: the bytes are
+    // never moved, only the label is read the other way round.
+    const bool relabelled = t.shape.size() == 2 && t.shape[0] == cols && t.shape[1] == rows && rows != cols &&
+                            abs_diff(avail, rows * ceil_div(cols, 256) * 64) <= 128;
+    if (t.shape.size() == 2 && (loader_is_qk256(t.shape, avail) || relabelled)) {
         // orientation: as-is or transposed LABEL (the bytes are never moved), gguf_simple.rs:318-362
         const bool ok = (t.shape[0] == rows && t.shape[1] == cols) || (t.shape[1] == rows && t.shape[0] == cols);
         if (!ok) {

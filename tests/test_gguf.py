@@ -265,3 +265,28 @@ def test_truncated_last_tensor_is_refused_not_read_past_the_file(pkg):
     f = pkg.GgufFile(data=W.write_gguf([], [tail, ("blk.0.attn_k.weight", (qrows, qcols), W.I2_S, bytes(qrows * 64))]))
     f.check_projection(1, qrows, qcols)
     f.close()
+
+
+def test_llama_cpp_labelled_qk256_is_taken_in_the_configured_orientation(pkg):
+    """k_proj of the Microsoft 2B file is labelled [2560, 640] (ne[0] = in first; the reference's tests/gqa_shapes.rs:22) while
+    its bytes are 640 rows of 10 blocks.  Read as labelled (2560 rows x 3 blocks) the per-row byte count is wrong, and the
+    reference's two passes leave such a tensor in neither map (restated in oracle/gguf_oracle.py).  The product loader takes
+    it in the orientation the model configuration names -- the bytes are not moved -- and keeps refusing a size that fits
+    neither orientation."""
+    rows, cols = 128, 640  # out, in: 3 blocks per row; as labelled (640, 128) it would be 640 rows of 1 block
+    good = bytes(rows * 3 * 64)
+    f = pkg.GgufFile(data=W.write_gguf([], [("blk.0.attn_k.weight", (cols, rows), W.I2_S, good), ("pad.weight", (16,), W.F32, bytes(64))]))
+    f.check_projection(0, rows, cols)
+    f.close()
+    f = pkg.GgufFile(data=W.write_gguf([], [("blk.0.attn_k.weight", (rows, cols), W.I2_S, good), ("pad.weight", (16,), W.F32, bytes(64))]))
+    f.check_projection(0, rows, cols)  # labelled [out, in]: the reference's own convention
+    f.close()
+    # the oracle (= the reference's two passes) drops the llama.cpp-labelled tensor
+    g = G.parse(W.write_gguf([], [("blk.0.attn_k.weight", (cols, rows), W.I2_S, good), ("pad.weight", (16,), W.F32, bytes(64))]))
+    t = g.info("blk.0.attn_k.weight")
+    assert not G.loader_is_qk256(t.shape, t.size)
+    # bytes that fit neither orientation
+    f = pkg.GgufFile(data=W.write_gguf([], [("blk.0.attn_k.weight", (cols, rows), W.I2_S, bytes(rows * 3 * 64 + 4096)), ("pad.weight", (16,), W.F32, bytes(64))]))
+    with pytest.raises(pkg.BitNetHipError):
+        f.check_projection(0, rows, cols)
+    f.close()

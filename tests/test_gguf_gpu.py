@@ -206,3 +206,50 @@ def test_coded_and_inline_uploads(hip, rows, cols):
             hip.weights_free(h)
     with pytest.raises(Exception, match="k % 32"):
         hip.weights_upload_inline_f16(bytes(100), 2, 40, (-2, -1, 0, 1), 0)
+
+
+def test_full_size_gguf_file_through_the_loader(pkg, synth, tmp_path):
+    """A file of the REAL model's size and tensor inventory (bitnet-b1.58-2B-4T: 30 blocks, 210 I2_S tensors in the QK256
+    flavour = 521 MB, a 657 MB f16 embedding table; 1.18 GB, offsets beyond 2^31) written with synthetic weights, ingested
+    by the product loader (mmap -> flavour per tensor -> device layout), against the same weights handed over through the
+    decoder's set_layer / set_globals entries: identical logits and greedy tokens.  (The real file is not available to this
+    build: tests/test_real_model.py takes it from $BITNET_GGUF.)"""
+    cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
+    cfg.max_pos = 64
+    glob = synth.make_globals(cfg)
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    tensors = [("token_embd.weight", (cfg.vocab, cfg.hidden), W.F16, glob["embed_f16"].tobytes()),
+               ("output_norm.weight", (cfg.hidden,), W.F32, glob["final_norm"].tobytes())]
+    for l, lay in enumerate(layers):
+        tensors.append((f"blk.{l}.attn_norm.weight", (cfg.hidden,), W.F32, lay["attn_norm"].tobytes()))
+        tensors.append((f"blk.{l}.ffn_norm.weight", (cfg.hidden,), W.F32, lay["ffn_norm"].tobytes()))
+        for name in PROJ:
+            rows, cols = cfg.shapes()[name]
+            shape = (cols, rows) if name in ("k", "v", "down") else (rows, cols)  # llama.cpp's ne[0] = in for some writers
+            tensors.append((f"blk.{l}.{W.BLK[name]}.weight", shape, W.I2_S, lay[name].tobytes()))
+    data = W.write_gguf(W.model_kvs(cfg), tensors)
+    assert len(data) > (1 << 30)
+    path = tmp_path / "synthetic_2b4t.gguf"
+    path.write_bytes(data)
+    del data, tensors
+    f = pkg.GgufFile(path=str(path))
+    c = f.config()
+    assert (c["hidden"], c["n_layers"], c["n_heads"], c["n_kv_heads"], c["ffn"], c["vocab"]) == (2560, 30, 20, 5, 6912, 128256)
+    a = pkg.HostDecoder(cfg)
+    a.load_gguf(f)
+    f.close()
+    path.unlink()  # nothing of the file is referenced after the upload
+    b = pkg.HostDecoder(cfg)
+    for l, lay in enumerate(layers):
+        b.set_layer_qk256(l, lay)
+    b.set_globals(glob)
+    prompt = synth.prompt(6, cfg.vocab)
+    for d in (a, b):
+        d.reset()
+        d.feed(prompt)
+        d.run(5, with_logits=False)
+        d.run(4, with_logits=True)
+    assert np.array_equal(a.last_logits(), b.last_logits())
+    assert list(a.history(10)) == list(b.history(10))
+    a.close()
+    b.close()
