@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -659,8 +660,19 @@ int load_gguf_into(Decoder &dec, const GgufFile &g) {
     if (!emb || !fin) return fail("missing token embedding or final norm tensor");
     if (emb->shape.size() != 2) return fail("token embedding must be 2-D");
     const size_t V = c.vocab;
-    const bool as_is = emb->shape[0] == V && emb->shape[1] == H, transposed = emb->shape[0] == H && emb->shape[1] == V;
+    bool as_is = emb->shape[0] == V && emb->shape[1] == H, transposed = emb->shape[0] == H && emb->shape[1] == V;
     if (!as_is && !transposed) return fail("token embedding has unexpected shape");
+    // The reference builds its tensors with the file's dimension order as row-major extents (gguf_simple.rs:1033-1073) and
+    // transposes a [hidden, vocab] embedding physically (:1483-1530) -- restated here.  A llama.cpp writer lists ne[0] = hidden
+    // FIRST for bytes that are already [vocab][hidden]; BITNET_GGUF_GGML_DIMS=1 reads such a label that way (no data
+    // movement).  Opt-in: which of the two the real Microsoft file needs cannot be checked in this build (no file).
+    if (transposed && !as_is) {
+        const char *e = getenv("BITNET_GGUF_GGML_DIMS");
+        if (e && e[0] == '1') {
+            as_is = true;
+            transposed = false;
+        }
+    }
     std::vector<uint16_t> table(V * H);
     const uint8_t *p = g.tensor_data(*emb);
     if (emb->type == GGUF_F16) {

@@ -253,3 +253,50 @@ def test_full_size_gguf_file_through_the_loader(pkg, synth, tmp_path):
     assert list(a.history(10)) == list(b.history(10))
     a.close()
     b.close()
+
+
+def test_embedding_label_in_ggml_order_is_opt_in(pkg, synth, tmp_path, monkeypatch):
+    """token_embd labelled [hidden, vocab] while the bytes are [vocab][hidden] (llama.cpp lists ne[0] first): by default the
+    loader restates the reference (dimension order = row-major extents, physical transpose, gguf_simple.rs:1483-1530), with
+    BITNET_GGUF_GGML_DIMS=1 it reads the label the ggml way and the model equals the directly uploaded one."""
+    cfg = synth.ModelConfig(**SMALL)
+    glob = synth.make_globals(cfg)
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    tensors = [("token_embd.weight", (cfg.hidden, cfg.vocab), W.F16, glob["embed_f16"].tobytes()),
+               ("output_norm.weight", (cfg.hidden,), W.F32, glob["final_norm"].tobytes())]
+    for l, lay in enumerate(layers):
+        tensors.append((f"blk.{l}.attn_norm.weight", (cfg.hidden,), W.F32, lay["attn_norm"].tobytes()))
+        tensors.append((f"blk.{l}.ffn_norm.weight", (cfg.hidden,), W.F32, lay["ffn_norm"].tobytes()))
+        for name in PROJ:
+            rows, cols = cfg.shapes()[name]
+            tensors.append((f"blk.{l}.{W.BLK[name]}.weight", (rows, cols), W.I2_S, lay[name].tobytes()))
+    data = W.write_gguf(W.model_kvs(cfg), tensors)
+    direct = pkg.HostDecoder(cfg)
+    for l, lay in enumerate(layers):
+        direct.set_layer_qk256(l, lay)
+    direct.set_globals(glob)
+    prompt = synth.prompt(4, cfg.vocab)
+
+    def logits_of(dec):
+        dec.reset()
+        dec.feed(prompt)
+        dec.run(3, with_logits=False)
+        dec.run(1, with_logits=True)
+        return dec.last_logits().copy()
+
+    want = logits_of(direct)
+    got = {}
+    for mode in ("reference", "ggml"):
+        if mode == "ggml":
+            monkeypatch.setenv("BITNET_GGUF_GGML_DIMS", "1")
+        else:
+            monkeypatch.delenv("BITNET_GGUF_GGML_DIMS", raising=False)
+        f = pkg.GgufFile(data=data)
+        dec = pkg.HostDecoder(cfg)
+        dec.load_gguf(f)
+        f.close()
+        got[mode] = logits_of(dec)
+        dec.close()
+    direct.close()
+    assert np.array_equal(got["ggml"], want)
+    assert not np.array_equal(got["reference"], want)  # the reference's reading transposes these bytes

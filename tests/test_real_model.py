@@ -5,6 +5,9 @@ docs/baselines/ggml-model-i2_s.fingerprint -- 1,187,801,280 bytes, sha256 4221b2
     BITNET_GGUF=/data/ggml-model-i2_s.gguf BITNET_TRACE_OUT=/tmp/trace python -m pytest tests/test_real_model.py -m gpu -q
     BITNET_GGUF=/data/ggml-model-i2_s.gguf python bench.py            # the same file through bench.py (data: "gguf:...")
 
+If the file lists the embedding as [hidden, vocab] (llama.cpp's ne[0]-first order) the loader restates the reference
+(physical transpose); BITNET_GGUF_GGML_DIMS=1 reads the label the ggml way instead (bytes already [vocab][hidden]).
+
 What it checks: the file's identity, that every I2_S tensor takes the flavour the reference's receipts name
 (ggml_qk256_no_scale), the fast decode step against the unfused exact-kernel step on the real weights (logits cosine),
 greedy decoding of 8 tokens (BASELINE configs[0]'s command), and it leaves the reference-format activation trace of the first
