@@ -37,7 +37,6 @@ void free_weights(Weights *w) {
     if (w->codes) (void)hipFree(w->codes);
     if (w->scales) (void)hipFree(w->scales);
     if (w->tiles) (void)hipFree(w->tiles);
-    if (w->tiles_k32) (void)hipFree(w->tiles_k32);
     if (w->scale_tiles) (void)hipFree(w->scale_tiles);
     if (w->scale_tiles_h) (void)hipFree(w->scale_tiles_h);
     if (w->ln_g) (void)hipFree(w->ln_g);
@@ -532,7 +531,6 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->codes = nullptr;
     f->scales = nullptr;
     f->tiles = nullptr;
-    f->tiles_k32 = nullptr;
     f->scale_tiles = nullptr;
     f->scale_tiles_h = nullptr;
     f->ln_g = nullptr;

@@ -69,9 +69,6 @@ struct Weights {
     // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
     // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
     uint8_t *tiles = nullptr;
-    // the same tiles with K re-dealt for v_mfma_i32_16x16x32_i8 (lane group g holds columns 8 g .. 8 g + 7 of EACH 32-block):
-    // only the tiled matmul of 32-block-scaled matrices reads it; built on its first use (kernels_gemm.hip)
-    uint8_t *tiles_k32 = nullptr;
     float *scale_tiles = nullptr;  // 32-block scales in tile order (kernels_mfma.hip k_retile_scales)
     // Every scale is exactly an f16 value (BitNet32-F16 files store them so): the streaming layout
     // keeps them as f16 (2 bytes per 32 weights instead of 4) -- same numbers, fewer bytes.

@@ -197,9 +197,11 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
 // lane groups of an MFMA's K = 64 belong to four different 32-blocks, so B is masked to one lane group at a
 // time (4x the MFMAs) and every pair of MFMAs is folded into f32 with its block's scale.
 // WS == 3: 32-block scales on v_mfma_i32_16x16x32_i8 -- one MFMA = one 32-weight block, no masking (the K = 64 form has four
-// different blocks in its four lane groups: WS == 2 masks B to one lane group at a time, 4x the MFMAs).  Needs the tiles dealt for
-// K = 32 (Weights::tiles_k32: lane group g holds columns 8 g .. 8 g + 7 of every 32-block; dword i of a lane = blocks 2 i and
-// 2 i + 1, so the GEMV's 16-code decode yields both blocks' 8-byte A operands) and reads its scales as f16 tiles.
+// different blocks in its four lane groups: WS == 2 masks B to one lane group at a time, 4x the MFMAs).  The K = 32 operand
+// wants lane group g to hold columns 8 g .. 8 g + 7 of a 32-block; in the GEMV's tiles those are eight 2-bit fields of ONE
+// dword of another lane (lane (r, i) for blocks 2 i and 2 i + 1): the wave passes its tiles through a private LDS area and
+// reads them back in that deal -- no second copy of the codes in HBM (fetching the 8 dwords per lane straight from global
+// memory instead cost 40 % of the prefill: 32 load instructions per K step).  Scales come as f16 tiles.
 // MINW = 4 waves per SIMD = two workgroups per CU (<= 128 registers): the narrow-token-tile form for launches whose wide-tile grid would
 // leave most CUs idle in its last round (a 2560-row matrix x 4096 tokens = 320 wide workgroups on 256 CUs).
 typedef unsigned gv4u __attribute__((ext_vector_type(4)));
@@ -293,6 +295,9 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
     // K = 32 form: this lane's f16 scale tiles, one 16-byte load per (row tile, 64 columns)
     const uint16_t *sptr[WS == 3 ? 4 : 1];
     gv4u scn[WS == 3 ? 4 : 1];
+    const int sh3 = 4 * (g & 1);  // this lane's columns are the low (g even) or high nibble half of each source byte
+    uint8_t *wst = lds + kBuf + wave * 4096;                                       // WS == 3: this wave's tile staging area
+    const uint8_t *wrd = wst + c * 16 + 4 * (g >> 1);                              //          and where this lane reads it back
     if (WS == 3) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
@@ -313,6 +318,13 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
             __syncthreads();  // the previous step's LDS reads are done
 #pragma unroll
             for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+            if (WS == 3) {
+                // the K = 32 operand of lane (r, g) is eight 2-bit fields of ONE dword of lane (r, i)'s 16 bytes (blocks 2 i,
+                // 2 i + 1): the wave's four 1-KiB tiles pass through a wave-private LDS area and are read back in that deal
+                // (the barrier below also orders these stores before the reads)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<gv4u *>(wst + rt * 1024 + lane * 16) = wn[rt];
+            }
             __syncthreads();
         } else {
             // tile blk is in buffer blk & 1 (everyone passed the barrier that ended step blk - 1, so nobody still
@@ -359,8 +371,13 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
                 v4i a[4];
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
-                    const uint32_t wd = i == 0 ? wc[rt].x : i == 1 ? wc[rt].y : i == 2 ? wc[rt].z : wc[rt].w;
-                    a[rt] = gdecode16(wd, p.lut);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        // dword 2 hb + (g >> 1) of lane (r, i): its elements 8 h .. 8 h + 7 (fields are transposed 4 x 4: a nibble half)
+                        const uint32_t wd = *reinterpret_cast<const uint32_t *>(wrd + rt * 1024 + i * 256 + 8 * hb) >> sh3;
+                        a[rt][2 * hb] = (int)__builtin_amdgcn_perm(0u, p.lut, wd & 0x03030303u);
+                        a[rt][2 * hb + 1] = (int)__builtin_amdgcn_perm(0u, p.lut, (wd >> 2) & 0x03030303u);
+                    }
                 }
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
@@ -522,49 +539,6 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
     }
 }
 
-// ---- tiles re-dealt for K = 32 MFMAs: out lane (r, g) dword i element e <- column 32 (2 i + (e >> 3)) + 8 g + (e & 7) of the block ----
-__device__ __forceinline__ uint32_t transpose_fields_g(uint32_t w) {  // 4 x 4 transpose of the sixteen 2-bit fields (an involution)
-    uint32_t o = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o |= ((w >> (2 * (4 * i + b))) & 3u) << (2 * (4 * b + i));
-    return o;
-}
-__global__ void k_retile_k32(const uint32_t *__restrict__ tiles, uint32_t *__restrict__ out, size_t total_dwords) {
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one output dword
-    if (id >= total_dwords) return;
-    const int i = (int)(id & 3), lane = (int)((id >> 2) & 63), r = lane & 15, g = lane >> 4;
-    const size_t tb = id >> 8;  // (tile, block): 256 dwords each
-    uint32_t w = 0;
-    for (int e = 0; e < 16; ++e) {
-        const int k = 32 * (2 * i + (e >> 3)) + 8 * g + (e & 7);               // column inside the 256-block
-        const int gs = k >> 6, ms = (k >> 4) & 3, es = k & 15;                   // source lane group, dword, element
-        const uint32_t src = transpose_fields_g(tiles[tb * 256 + (size_t)(16 * gs + r) * 4 + ms]);  // natural field order
-        w |= ((src >> (2 * es)) & 3u) << (2 * e);
-    }
-    out[id] = transpose_fields_g(w);
-}
-static hipError_t ensure_tiles_k32(const Weights &cw, hipStream_t stream) {
-    Weights &w = const_cast<Weights &>(cw);  // a lazily built cache of the same matrix
-    std::lock_guard<std::mutex> lk(*w.mu);
-    if (w.tiles_k32) return hipSuccess;
-    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256), total = n_tiles * nblk * 256;
-    uint8_t *buf = nullptr;
-    hipError_t e = hipMalloc((void **)&buf, total * 4);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_retile_k32, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(w.tiles),
-                       reinterpret_cast<uint32_t *>(buf), total);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) {
-        (void)hipFree(buf);
-        return e;
-    }
-    w.tiles_k32 = buf;
-    return hipSuccess;
-}
-
 // ---- host side ---------------------------------------------------------------------------------
 constexpr size_t kGemmCUs = 256;
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
@@ -607,7 +581,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             ttw = 2;
         }
     }
-    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2);  // unscaled variant: double-buffered
+    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2) + (k32 ? 8 * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -626,10 +600,6 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     const bool k32 = gemm_k32(w);
     const int ws_mode = !w.scaled ? 0 : w.block_size == 32 ? 2 : 1;
     if (gemm_needs_row_major_scales(w) && !w.scales) return hipErrorInvalidValue;  // the caller materialises them (ensure_reference)
-    if (k32) {
-        const hipError_t e = ensure_tiles_k32(w, stream);
-        if (e != hipSuccess) return e;
-    }
     const size_t wg_tokens = (size_t)32 * gemm_ttw(ndig, ws_mode), m_pad = div_ceil(m, wg_tokens) * wg_tokens;
     QuantArgs q;
     q.x = x;
@@ -644,7 +614,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     q.inv_scale = reinterpret_cast<float *>(ws);
     q.planes = reinterpret_cast<int8_t *>(ws + div_ceil(m_pad * 4, 256) * 256);
     GemmArgs a;
-    a.tiles = k32 ? w.tiles_k32 : w.tiles;
+    a.tiles = w.tiles;
     a.stiles_h = k32 ? w.scale_tiles_h : nullptr;
     a.rows = (int)w.rows;
     a.cols = (int)w.cols;

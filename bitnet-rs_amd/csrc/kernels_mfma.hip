@@ -839,7 +839,6 @@ size_t weights_device_bytes(const Weights &w) {
     if (w.codes) b += w.rows * w.row_stride_bytes;
     if (w.scales) b += w.rows * w.nblk * sizeof(float);
     if (w.tiles) b += n_tiles * nblk * 1024;
-    if (w.tiles_k32) b += n_tiles * nblk * 1024;
     if (w.scale_tiles) b += n_tiles * nblk * 128 * sizeof(float);
     if (w.scale_tiles_h) b += n_tiles * nblk * 128 * sizeof(uint16_t);
     if (w.ln_g) b += w.rows * sizeof(float);
@@ -856,10 +855,6 @@ void trim_reference(Weights &w) {
     if (w.scales && w.scaled && w.block_size == 32 && (w.scale_tiles || w.scale_tiles_h)) {
         (void)hipFree(w.scales);
         w.scales = nullptr;
-    }
-    if (w.tiles_k32) {  // the tiled matmul's K = 32 deal of the same codes (kernels_gemm.hip rebuilds it on its next use)
-        (void)hipFree(w.tiles_k32);
-        w.tiles_k32 = nullptr;
     }
 }
 

@@ -196,9 +196,7 @@ int bitnet_hip_weights_info(bitnet_hip_weights_t w, size_t *rows, size_t *cols,
 /* Device memory behind a handle.  The streaming layout (1-KiB code tiles + scale tiles) is the only copy kept: the
  * reference-layout copy the reference-order kernels (BITNET_HIP_KERNEL_EXACT / _VALU) and the tiled matmul's 32-element
  * scales read is rebuilt on their first use (exact inverse permutation; that call synchronises its stream once) and stays
- * until bitnet_hip_weights_trim drops it again.  A matrix with 32-element scales that runs the tiled matmul (prefill)
- * additionally gets its codes re-dealt for the K = 32 matrix-core instruction on first use (one more code-sized buffer,
- * also dropped by _trim).  Nothing a host does concurrently on OTHER handles is affected. */
+ * until bitnet_hip_weights_trim drops it again.  Nothing a host does concurrently on OTHER handles is affected. */
 size_t bitnet_hip_weights_device_bytes(bitnet_hip_weights_t w);
 int bitnet_hip_weights_trim(bitnet_hip_weights_t w);
 

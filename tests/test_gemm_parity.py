@@ -135,16 +135,9 @@ def test_ternary_scaled_gemm(hip, oracle, torch_, block, f16_scales, n, k, m):
     got = run_gemm(hip, torch_, h, x, n, 2)  # 16-bit activations: 2^-15 of each row's maximum per element
     assert np.max(np.abs(got - want)) <= 2e-4 * np.max(np.abs(want)) + 1e-6, (block, 2)
     if block == 32 and f16_scales and k % 256 == 0:
-        # the K = 32 deal of the codes is a lazily built cache: one more code-sized buffer, dropped by weights_trim and
-        # rebuilt by the next tiled matmul with identical results
+        # the K = 32 path reads the GEMV tiles and the f16 scale tiles: no second copy of the codes, no row-major scales
         code_bytes = -(-n // 16) * (k // 256) * 1024
-        full = hip.weights_device_bytes(h)
-        hip.weights_trim(h)
-        trimmed = hip.weights_device_bytes(h)
-        assert full - trimmed >= code_bytes
-        again = run_gemm(hip, torch_, h, x, n, 2)
-        assert np.array_equal(again, got)
-        assert hip.weights_device_bytes(h) == trimmed + code_bytes  # only the K = 32 tiles came back: this path reads scale tiles, not row-major scales
+        assert hip.weights_device_bytes(h) < 2 * code_bytes
     hip.weights_free(h)
 
 
