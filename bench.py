@@ -366,6 +366,7 @@ def main():
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": load_traffic(args.workload),
+        "traffic_source": f"profiles/traffic_{args.workload}.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench's own launch path (tools/profile_round.sh), per launch; not collected inside this run",
         "bytes_per_launch": int(abytes),
         "us_per_launch": round(us, 3),
     }
