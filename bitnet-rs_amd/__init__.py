@@ -138,6 +138,7 @@ class HipLib:
         L.bitnet_hip_gemv_q_dev.argtypes = [C.c_uint64, _vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_attention_decode_q_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, C.c_int, _vp, _vp, _vp]
         L.bitnet_hip_gemv_attn_merge_q_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.bitnet_hip_gemv_attn_merge_wide_q_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
@@ -396,8 +397,8 @@ class HipLib:
                                                  _optr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
     def attention_decode_q_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, pos, scratch, out, qact_out,
-                               wide: bool = False, kv_f16: bool = False, stream: int = 0) -> None:
-        flags = (1 if wide else 0) | (2 if kv_f16 else 0)
+                               wide: bool = False, kv_f16: bool = False, stream: int = 0, partial: bool = False) -> None:
+        flags = (1 if wide else 0) | (2 if kv_f16 else 0) | (4 if partial else 0)  # BITNET_HIP_ATTN_WIDE / _KV_F16 / _PARTIAL
         self._check(self.c.bitnet_hip_attention_decode_q_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
                                                              head_dim, max_pos, _ptr(pos), _ptr(scratch), flags, _optr(out), _optr(qact_out), _vp(stream)))
 
@@ -405,6 +406,12 @@ class HipLib:
                               stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_gemv_attn_merge_q_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _optr(residual),
                                                             _ptr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
+
+    def gemv_attn_merge_wide_q_dev(self, h: int, scratch, n_heads, n_kv, max_pos, pos, y, qact_out, residual=None, gamma_out=None,
+                                   stats_out=None, stream: int = 0) -> None:
+        """the same on 128-position records (attention_decode_q_dev with ATTN_WIDE | ATTN_PARTIAL): up to 512 keys"""
+        self._check(self.c.bitnet_hip_gemv_attn_merge_wide_q_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _optr(residual),
+                                                                 _ptr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
     def weights_concat(self, parts, interleave16: bool = False) -> int:
         arr = (C.c_uint64 * len(parts))(*parts)

@@ -766,10 +766,11 @@ int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_
 }
 
 size_t bitnet_hip_attention_merge_max_keys(void) { return (size_t)4 * 64; }
+size_t bitnet_hip_attention_merge_max_keys_wide(void) { return (size_t)4 * 128; }
 
 static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads, size_t max_pos,
                            const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out, const float *gamma_out_dev,
-                           double *stats_out, void *stream) {
+                           double *stats_out, void *stream, int chunk_log2 = 6) {
     BH_GUARD_BEGIN
     const WeightsRef w = lookup(h);
     if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
@@ -792,7 +793,8 @@ static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev
         io.stats_out = stats_out;
         io.attn_rec = attn_scratch_dev;
         io.attn_pos = pos_dev;
-        io.attn_chunks_max = (int)div_ceil(max_pos, (size_t)64);
+        io.attn_chunk_log2 = chunk_log2;
+        io.attn_chunks_max = (int)div_ceil(max_pos, (size_t)1 << chunk_log2);
         io.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
         hipError_t e = launch_gemv_q(*w, io, (hipStream_t)stream);
         if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
@@ -802,7 +804,7 @@ static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev
     fu.residual = residual_dev;
     fu.attn_rec = attn_scratch_dev;
     fu.attn_pos = pos_dev;
-    fu.attn_chunk_log2 = 6;
+    fu.attn_chunk_log2 = chunk_log2;
     fu.attn_chunks_max = (int)div_ceil(max_pos, (size_t)1 << fu.attn_chunk_log2);
     fu.attn_group_log2 = group == 4 ? 2 : group == 2 ? 1 : 0;
     fu.qout = qact_out;
@@ -822,6 +824,13 @@ int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t h, const float *attn_s
                                      const float *gamma_out_dev, double *stats_out, void *stream) {
     if (!qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_q_dev");
     return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, qact_out, gamma_out_dev, stats_out, stream);
+}
+
+int bitnet_hip_gemv_attn_merge_wide_q_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
+                                          size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out,
+                                          const float *gamma_out_dev, double *stats_out, void *stream) {
+    if (!qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_wide_q_dev");
+    return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, qact_out, gamma_out_dev, stats_out, stream, 7);
 }
 
 /* ---- QAct: activations quantised by their producer (csrc/qact.hpp) ---- */

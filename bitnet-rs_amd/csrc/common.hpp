@@ -117,7 +117,7 @@ struct GemvQIo {
     // instead of qin: the decode attention's chunk records, merged by the GEMV itself (short contexts, <= 4 records)
     const float *attn_rec = nullptr;
     const int *attn_pos = nullptr;
-    int attn_chunks_max = 0, attn_group_log2 = 0;
+    int attn_chunks_max = 0, attn_group_log2 = 0, attn_chunk_log2 = 6;  // positions per record = 1 << attn_chunk_log2
 };
 
 // ---- kernel launchers (kernels_*.hip) -------------------------------------

@@ -114,7 +114,7 @@ struct GemvQArgs {
     // (launch_attn_decode(..., combine = false): (m, l)[4] + un-normalised P.V [4][128] per KV head and 64-position chunk)
     const float *attn_rec;
     const int *attn_pos;     // *attn_pos + 1 keys
-    int attn_chunks_max, attn_group_log2;
+    int attn_chunks_max, attn_group_log2, attn_chunk_log2;  // records per KV head, log2 heads per KV head, log2 positions per record (6 / 7)
     unsigned long long *stamps;  // diagnostic builds only
 };
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q(GemvQArgs p) {
 #pragma unroll
         for (int i = 0; i < NCP; ++i) *reinterpret_cast<v4u *>(cq + 16 * (tid + NT * i)) = qa[i];
     } else {
-        const int m_chunks = (*p.attn_pos + 64) >> 6;  // live records, 1..4 (the caller switches to the combine kernel beyond that)
+        const int m_chunks = (*p.attn_pos + (1 << p.attn_chunk_log2)) >> p.attn_chunk_log2;  // live records, 1..4 (the caller switches to the combine kernel beyond that)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = 4 * (tid + NT * i);
@@ -499,6 +499,7 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
     a.attn_pos = io.attn_pos;
     a.attn_chunks_max = io.attn_chunks_max;
     a.attn_group_log2 = io.attn_group_log2;
+    a.attn_chunk_log2 = io.attn_chunk_log2;
     a.stamps = g_mfma_stamps;
     if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
     const int tiles_per_wg = nw / ksplit;
