@@ -340,6 +340,9 @@ def main():
     else:
         dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
         dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
+    if use_graph:
+        dec.prepare_graphs(True)  # every attention form's step graph is built up front (a form first met inside the timed steps
+                                  # would otherwise be captured there: ~2 ms of host work, not part of a decode step)
     dec.run(args.warmup, with_logits=True, use_graph=use_graph)      # W untimed warm-up steps
 
     ev = {}

@@ -630,6 +630,7 @@ class HostDecoder:
         L.bitnet_host_feed.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.bitnet_host_run_reference.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bitnet_host_prepare_graphs.argtypes = [C.c_void_p, C.c_int]
         L.bitnet_host_set_act_mode.argtypes = [C.c_void_p, C.c_int]
         L.bitnet_host_act_mode.argtypes = [C.c_void_p]
         L.bitnet_host_position.argtypes = [C.c_void_p]
@@ -712,6 +713,10 @@ class HostDecoder:
         self.c.bitnet_host_trace_step.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         os.makedirs(directory, exist_ok=True)
         self._check(self.c.bitnet_host_trace_step(self.h, directory.encode(), int(with_logits)))
+
+    def prepare_graphs(self, with_logits: bool = True) -> None:
+        """capture + instantiate the step graph of every attention form a sequence can reach, ahead of time (nothing executes)"""
+        self._check(self.c.bitnet_host_prepare_graphs(self.h, int(with_logits)))
 
     def run_reference(self, n: int, with_logits: bool = True) -> None:
         """n UNFUSED steps on the bit-exact reference-order kernels (the checker of the fast step; slow)."""

@@ -616,6 +616,19 @@ int Decoder::form_at(int pos) const {
     return 0;
 }
 
+int Decoder::prepare_graphs(bool with_logits) {
+    if (!embed_) {
+        err_ = "model globals not set";
+        return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    }
+    unsigned forms = 0;
+    for (int pos = 0; pos + 1 < c_.max_pos; ++pos) forms |= 1u << form_at(pos);
+    for (int f = 0; f < kGraphs / 2; ++f)
+        if (forms & (1u << f))
+            if (int rc = ensure_graph(with_logits, f)) return rc;
+    return 0;
+}
+
 int Decoder::ensure_graph(bool with_logits, int form) {
     const int gi = 2 * form + (with_logits ? 1 : 0);
     if (graph_exec_[gi]) return 0;
@@ -1078,6 +1091,7 @@ int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast
 int bitnet_host_set_kv_f16(void *d, int on) { return static_cast<Decoder *>(d)->set_kv_f16(on != 0); }
 int bitnet_host_set_act_mode(void *d, int mode) { return static_cast<Decoder *>(d)->set_act_mode(mode); }
 int bitnet_host_act_mode(void *d) { return static_cast<Decoder *>(d)->qact_path() ? 1 : 0; }
+int bitnet_host_prepare_graphs(void *d, int with_logits) { return static_cast<Decoder *>(d)->prepare_graphs(with_logits != 0); }
 int bitnet_host_run_reference(void *d, int n, int with_logits) { return static_cast<Decoder *>(d)->run_reference(n, with_logits != 0); }
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
     return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);

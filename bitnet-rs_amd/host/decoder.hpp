@@ -145,6 +145,11 @@ class Decoder {
     int step_launches(bool with_logits, int form, Tracer *tr = nullptr);
     int step_launches_reference(bool with_logits);
     int ensure_graph(bool with_logits, int form);
+  public:
+    // Captures and instantiates the step graph of every attention form a sequence can reach (by position: form_at) ahead of
+    // time, so that no run() pays for a capture in the middle of a generation.  Nothing executes.
+    int prepare_graphs(bool with_logits);
+  private:
     int form_at(int pos) const;
     bool merge_ok_ = false;  // the o-projection can merge the attention chunk records itself (short contexts)
 
@@ -213,6 +218,7 @@ int bitnet_host_reset(void *d);
 int bitnet_host_feed(void *d, const int32_t *tokens, int n);
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms);
 int bitnet_host_run_reference(void *d, int n, int with_logits);
+int bitnet_host_prepare_graphs(void *d, int with_logits);
 int bitnet_host_set_act_mode(void *d, int mode);
 int bitnet_host_set_kv_f16(void *d, int on);
 int bitnet_host_act_mode(void *d);
