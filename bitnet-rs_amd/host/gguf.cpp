@@ -507,8 +507,10 @@ bool make_spec(const GgufFile &g, const GgufTensor &t, size_t rows, size_t cols,
     // it as QK256 -- it ends up in neither map.  The device path takes it in the orientation the model configuration
     // names (expected_qk256_shape, qk256_utils.rs:19-55) when THAT orientation's per-row byte count matches: the bytes are
     // never moved, only the label is read the other way round.
+    const size_t relabel_need = rows * ceil_div(cols, 256) * 64;
     const bool relabelled = t.shape.size() == 2 && t.shape[0] == cols && t.shape[1] == rows && rows != cols &&
-                            abs_diff(avail, rows * ceil_div(cols, 256) * 64) <= 128;
+                            abs_diff(avail, relabel_need) <= 128 &&
+                            abs_diff(avail, relabel_need) < abs_diff(avail, ceil_div(rows * cols, 32) * 10);  // the loader's own QK256-vs-inline tie-break
     if (t.shape.size() == 2 && (loader_is_qk256(t.shape, avail) || relabelled)) {
         // orientation: as-is or transposed LABEL (the bytes are never moved), gguf_simple.rs:318-362
         const bool ok = (t.shape[0] == rows && t.shape[1] == cols) || (t.shape[1] == rows && t.shape[0] == cols);
