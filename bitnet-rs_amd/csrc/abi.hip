@@ -99,8 +99,39 @@ int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvF
     if ((kernel == BITNET_HIP_KERNEL_MFMA || kernel == BITNET_HIP_KERNEL_MFMA_TILED) && !mfma_supported(w))
         kernel = BITNET_HIP_KERNEL_VALU;
     if (kernel == BITNET_HIP_KERNEL_VALU && !valu_supported(w)) kernel = BITNET_HIP_KERNEL_EXACT;
-    if ((fu.ln_gamma || fu.residual || fu.silu_mul || fu.attn_rec) && kernel != BITNET_HIP_KERNEL_MFMA && kernel != BITNET_HIP_KERNEL_MFMA_TILED)
-        return set_error(BITNET_HIP_ERR_UNSUPPORTED, "fused LayerNorm/residual needs the MFMA GEMV (shape %zux%zu unsupported)", w.rows, w.cols);
+    if ((fu.ln_gamma || fu.residual || fu.silu_mul || fu.attn_rec) && kernel != BITNET_HIP_KERNEL_MFMA && kernel != BITNET_HIP_KERNEL_MFMA_TILED) {
+        // A shape (or a kernel choice) the fused MFMA GEMV does not take: the same result as separate launches on the device --
+        // LayerNorm rows, the product, silu * mul, residual add (the reference's own op order) -- through stream-ordered scratch.
+        if (fu.attn_rec || fu.qout)
+            return set_error(BITNET_HIP_ERR_UNSUPPORTED, "the merging / QAct forms need the MFMA GEMV (shape %zux%zu unsupported)", w.rows, w.cols);
+        if (fu.silu_mul && (!w.paired || fu.residual)) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_SILU_MUL needs an interleaved (gate, up) handle and no residual");
+        float *xn = nullptr, *yt = nullptr;
+        hipError_t e = hipSuccess;
+        auto done = [&](int rc) {
+            if (xn) (void)hipFreeAsync(xn, stream);
+            if (yt) (void)hipFreeAsync(yt, stream);
+            return rc;
+        };
+        const float *xin = x_dev;
+        if (fu.ln_gamma) {
+            e = hipMallocAsync((void **)&xn, m * w.cols * sizeof(float), stream);
+            if (e == hipSuccess) e = launch_norm_rows(x_dev, fu.ln_gamma, xn, (int)m, (int)w.cols, fu.ln_eps, false, stream);
+            if (e != hipSuccess) return done(set_error(BITNET_HIP_ERR_GPU, "LayerNorm ahead of the GEMV failed: %s", hipGetErrorString(e)));
+            xin = xn;
+        }
+        float *yout = y_dev;
+        if (fu.silu_mul) {
+            e = hipMallocAsync((void **)&yt, m * w.rows * sizeof(float), stream);
+            if (e != hipSuccess) return done(set_error(BITNET_HIP_ERR_GPU, "scratch allocation failed: %s", hipGetErrorString(e)));
+            yout = yt;
+        }
+        const int rc = run_gemv(w, xin, yout, m, GemvFusion{}, stream, kernel);
+        if (rc != BITNET_HIP_OK) return done(rc);
+        if (fu.silu_mul) e = launch_silu_mul(yt, yt + 16, y_dev, m * (w.rows / 2), 16, stream);
+        if (e == hipSuccess && fu.residual) e = launch_add(y_dev, fu.residual, y_dev, m * w.rows, stream);
+        if (e != hipSuccess) return done(set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e)));
+        return done(BITNET_HIP_OK);
+    }
     hipError_t e;
     if (kernel == BITNET_HIP_KERNEL_MFMA_TILED || kernel == BITNET_HIP_KERNEL_MFMA) {
         e = build_tiles(w, stream);  // no-op after the first call (done at upload normally)

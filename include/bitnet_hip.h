@@ -228,7 +228,8 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
 int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts, int interleave16,
                               bitnet_hip_weights_t *out);
 
-/* GEMV with the neighbouring decode-step work fused in (MFMA kernel):
+/* GEMV with the neighbouring decode-step work fused in (MFMA kernel; a matrix shape that kernel does not take -- e.g. 32-element
+ * scales with cols % 256 != 0 -- gets the same result from separate device launches in the reference's op order):
  *   ln_gamma != NULL : x <- LayerNorm(x) first -- no bias, WITH mean subtraction,
  *                      (x-mean)/sqrt(mean((x-mean)^2)+eps)*gamma  (T:67-100, T:1015, T:1104)
  *   residual != NULL : y = residual + W x                        (T:1073, T:1125)

@@ -403,3 +403,55 @@ def test_gemv_qk256_property(hip, pkg, oracle):
         assert np.array_equal(got2, got * np.float32(4.0)), (rows, cols, seed, scale)
 
     run()
+
+
+def test_fused_entries_on_shapes_outside_the_mfma_gemv(hip, pkg, oracle):
+    """gemv_fused_dev / matmul_fused_dev on matrices the fused MFMA GEMV does not take (32-element scales with cols % 256 != 0):
+    the library composes LayerNorm rows -> product -> silu * mul / residual add from separate device launches -- the reference's
+    own op order -- instead of refusing.  Found by tools/random_sweep.py."""
+    import torch
+
+    rng = np.random.default_rng(77)
+
+    def ternary(rows, cols):
+        codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(rows, cols), p=[0.5, 0.25, 0.25])
+        packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8).reshape(-1)
+        scales = rng.uniform(0.05, 1.5, rows * (cols // 32)).astype(np.float16).astype(np.float32)
+        return packed, scales
+
+    for rows, cols, m, ln, res in [(100, 64, 3, True, True), (16, 288, 1, False, True), (333, 32, 2, True, False), (1, 288, 17, True, True)]:
+        packed, scales = ternary(rows, cols)
+        h = hip.weights_upload_i2s(packed, scales, rows, cols, 32)
+        x = rng.uniform(-4, 4, (m, cols)).astype(np.float32)
+        gam = rng.uniform(0.5, 1.5, cols).astype(np.float32)
+        resid = rng.normal(0, 1, (m, rows)).astype(np.float32)
+        xin = np.stack([oracle.layernorm(x[i], gam, 1e-5) for i in range(m)]) if ln else x
+        want = oracle.i2s_matmul(xin.reshape(-1), packed, scales, m, rows, cols, 32).reshape(m, rows) + (resid if res else 0.0)
+        xd, gd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(gam).cuda(), torch.from_numpy(resid).cuda()
+        yd = torch.full((m, rows), float("nan"), device="cuda")
+        if m == 1:
+            hip.gemv_fused_dev(h, xd, yd, 1, gd if ln else None, 1e-5, rd if res else None, 0)
+        else:
+            wsb = hip.matmul_workspace_bytes(m, cols, 3)
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, ln_gamma=gd if ln else None, ln_eps=1e-5, residual=rd if res else None, digits=3)
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        assert np.max(np.abs(got - want)) <= 3e-5 * max(1.0, np.max(np.abs(want))) + 2e-4, (rows, cols, m)
+        hip.weights_free(h)
+    # silu(gate) * up on an interleaved pair of such matrices
+    rows, cols = 32, 288
+    (pg, sg), (pu, su) = ternary(rows, cols), ternary(rows, cols)
+    hg, hu = hip.weights_upload_i2s(pg, sg, rows, cols, 32), hip.weights_upload_i2s(pu, su, rows, cols, 32)
+    pair = hip.weights_concat([hg, hu], interleave16=True)
+    x = rng.uniform(-2, 2, cols).astype(np.float32)
+    g = oracle.i2s_matmul(x, pg, sg, 1, rows, cols, 32).astype(np.float64)
+    u = oracle.i2s_matmul(x, pu, su, 1, rows, cols, 32).astype(np.float64)
+    want = g / (1.0 + np.exp(-g)) * u
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((rows,), float("nan"), device="cuda")
+    hip.gemv_fused_dev(pair, xd, yd, 1, None, 0.0, None, 1)  # BITNET_HIP_FUSE_SILU_MUL
+    torch.cuda.synchronize()
+    assert np.max(np.abs(yd.cpu().numpy() - want)) <= 3e-5 * max(1.0, np.max(np.abs(want)))
+    for hh in (pair, hg, hu):
+        hip.weights_free(hh)

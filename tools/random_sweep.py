@@ -35,21 +35,47 @@ for case in range(n_cases):
         want = oracle.i2s_matmul(x.reshape(-1), packed, scales, m, rows, cols, block).reshape(m, rows)
     xd = torch.from_numpy(x).cuda()
     yd = torch.full((m, rows), float("nan"), device="cuda")
-    try:
-        if m == 1:
-            hip.gemv_dev(h, xd, yd)
+    # half of the cases through the fused entry points: LayerNorm prologue (cols >= 32) and / or residual epilogue, random digit count
+    fused = bool(rng.integers(0, 2))
+    ln = fused and cols >= 32 and bool(rng.integers(0, 2))
+    res = fused and bool(rng.integers(0, 2))
+    digits = int(rng.choice([2, 3, 4]))
+    if fused:
+        gam = rng.uniform(0.5, 1.5, cols).astype(np.float32)
+        resid = rng.normal(0, 1, (m, rows)).astype(np.float32)
+        xin = np.stack([oracle.layernorm(x[i], gam, 1e-5) for i in range(m)]) if ln else x
+        if fmt == "qk256":
+            want = np.stack([oracle.gemv_qk256(qs, xin[i], rows, cols, stride) for i in range(m)])
         else:
-            hip.matmul_dev(h, xd, yd, m)
+            want = oracle.i2s_matmul(xin.reshape(-1), packed, scales, m, rows, cols, block).reshape(m, rows)
+        if res:
+            want = want + resid
+    try:
+        if not fused:
+            if m == 1:
+                hip.gemv_dev(h, xd, yd)
+            else:
+                hip.matmul_dev(h, xd, yd, m)
+        else:
+            gd, rd = torch.from_numpy(gam).cuda(), torch.from_numpy(resid).cuda()
+            if ln and bool(rng.integers(0, 2)):
+                hip.weights_bind_ln(h, gd)  # LayerNorm applied after the product (bound g = W . gamma)
+            if m == 1:
+                hip.gemv_fused_dev(h, xd, yd, 1, gd if ln else None, 1e-5, rd if res else None, 0)
+            else:
+                wsb = hip.matmul_workspace_bytes(m, cols, digits)
+                ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+                hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, ln_gamma=gd if ln else None, ln_eps=1e-5, residual=rd if res else None, digits=digits)
         torch.cuda.synchronize()
         got = yd.cpu().numpy()
-        tol = 3e-5 * max(1.0, float(np.max(np.abs(want)))) + 2e-4 * np.sqrt(cols / 256.0)
+        tol = (3e-5 if not (fused and m > 1 and digits == 2) else 3e-4) * max(1.0, float(np.max(np.abs(want)))) + 2e-4 * np.sqrt(cols / 256.0)
         err = float(np.max(np.abs(got - want)))
         ok = np.isfinite(got).all() and err <= tol
-    except Exception as e:  # noqa: BLE001
+    except pkg.BitNetHipError as e:
         ok, err, tol = False, repr(e), 0
     if not ok:
         bad += 1
-        print("FAIL", fmt, rows, cols, m, err, tol, flush=True)
+        print("FAIL", fmt, rows, cols, m, "fused" if fused else "plain", "ln" if ln else "", "res" if res else "", digits, err, tol, flush=True)
     hip.weights_free(h)
 print(f"{n_cases - bad}/{n_cases} cases agree with the oracle", flush=True)
 sys.exit(1 if bad else 0)
