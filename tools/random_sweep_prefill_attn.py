@@ -1,0 +1,35 @@
+"""Developer tool (GPU box): the whole-sequence attention drop-in (bitnet_hip_attention = fused_attention_hip, K/rocm/attention.rs:54-65:
+q, k, v [batch, heads, seq, 128] f32, causal flag, scale) at random batch / head / sequence sizes against f64 numpy.
+python tools/random_sweep_prefill_attn.py [n] [seed]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("bitnet-rs_amd")
+hip = pkg.load(); hip.init(0)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+D, bad = 128, 0
+for case in range(n_cases):
+    batch, heads = int(rng.choice([1, 1, 2, 3])), int(rng.choice([1, 2, 3, 4, 5, 8]))
+    seq = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128, 129, 200, 333, 512, 700]))
+    causal = bool(rng.integers(0, 2))
+    scale = float(rng.choice([1.0 / np.sqrt(D), 0.05, 0.2]))
+    q, k, v = (rng.normal(0, 1.2, (batch, heads, seq, D)).astype(np.float32) for _ in range(3))
+    try:
+        got = hip.attention(q, k, v, seq, heads, D, causal=causal, scale=scale).reshape(batch, heads, seq, D).astype(np.float64)
+        q64, k64, v64 = q.astype(np.float64), k.astype(np.float64), v.astype(np.float64)
+        s = np.einsum("bhqd,bhkd->bhqk", q64, k64) * scale
+        if causal:
+            s = np.where(np.tril(np.ones((seq, seq), bool))[None, None], s, -np.inf)
+        p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+        want = np.einsum("bhqk,bhkd->bhqd", p, v64)
+        err = float(np.max(np.abs(got - want)))
+        ok = np.isfinite(got).all() and err <= 8e-3  # q, k, v, p go through the matrix cores as f16 (2^-11 relative each)
+    except pkg.BitNetHipError as e:
+        ok, err = False, repr(e)
+    if not ok:
+        bad += 1
+        print("FAIL", batch, heads, seq, "causal" if causal else "full", scale, err, flush=True)
+print(f"{n_cases - bad}/{n_cases} cases agree", flush=True)
+sys.exit(1 if bad else 0)
