@@ -174,44 +174,59 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     }
 }
 
-// 8 waves per workgroup = HW query heads of ONE KV head x (8 / HW) groups of 16 queries: all of them multiply the
-// same K / V^T tiles, so a tile is staged into LDS once for 128 (query, head) pairs (GQA with 4 heads per KV head:
-// 4 heads x 32 queries) -- the kernel is bound by the tile traffic L2 -> CU, not by the matrix cores.
-template <int HW, int NW>
-__global__ __launch_bounds__(NW * 64) void k_prefill_attn(PrefillArgs p) {
-    constexpr int QW = NW / HW, QG = 16 * QW;  // query groups of 16 per workgroup, queries per workgroup
-    constexpr int NT = NW * 64;
+// NW waves per workgroup = HW query heads of ONE KV head x (NW / HW) wave columns; a wave owns NQ groups of 16 queries of its
+// head.  All waves multiply the same K / V^T tiles, staged into LDS once per workgroup.
+// Every MFMA takes its A operand (16 keys x 32 dims = 1 KiB per wave) from LDS, and those reads are what bounds this kernel
+// (ablation, 4096 tokens: 238 us; without the operand reads 137; without softmax arithmetic 218; without tile staging 205;
+// MFMAs alone ~100): with ONE query group per wave the reads need 64 B/clk per SIMD of a CU's 128 B/clk.  NQ = 2 lets two
+// query groups share each operand read.  That takes ~240 registers, so the GQA form runs 4-wave workgroups (4 heads x 32
+// queries) with a launch bound of two waves per SIMD: TWO workgroups per CU with independent barriers (one in its softmax
+// while the other multiplies).  The next key tile is requested into registers one iteration ahead and the LDS operand reads
+// are pinned one chunk ahead of their MFMAs (hipcc's own schedule waited for every read right before its MFMAs).
+typedef unsigned pv4u __attribute__((ext_vector_type(4)));
+
+template <int HW, int NW, int NQ>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(PrefillArgs p) {
+    constexpr int QW = NW / HW, QG = 16 * QW * NQ;  // wave columns per workgroup, queries per workgroup
+    constexpr int NT = NW * 64, NLD = 1024 / NT;
     __shared__ __attribute__((aligned(16))) uint8_t ks[kQB * kKPitch];
     __shared__ __attribute__((aligned(16))) uint8_t vs[kPD * kVPitch];
     __shared__ int s_last;
     const int qg = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int h = blockIdx.y * HW + wave % HW, kvh = h / (p.n_heads / p.n_kv);  // HW divides the group: one KV head per workgroup
-    const int qbase = qg * QG + (wave / HW) * 16;                 // first query row of this wave
-    const int qrow = qbase + c;                                   // this lane's query row (B-operand column)
+    const int qbase = qg * QG + (wave / HW) * 16 * NQ;            // first query row of this wave (16 NQ rows inside one 64-row block)
     const int blk64 = qbase >> 6;                                 // the 64-row block the wave's rows lie in
     const int bpos = (p.q_block_pos ? p.q_block_pos[blk64 < (p.nq + kQB - 1) / kQB ? blk64 : 0] : blk64 * kQB) + (qbase & 63);
-    const int qpos = bpos + c;
     if (tid == 0) s_last = 0;
     __syncthreads();
     {   // last key tile any query of the workgroup sees
-        const int need = p.causal ? (bpos + 15 < p.T ? bpos + 15 : p.T - 1) / kQB : (p.T - 1) / kQB;
+        const int top = bpos + 16 * NQ - 1;
+        const int need = p.causal ? (top < p.T ? top : p.T - 1) / kQB : (p.T - 1) / kQB;
         if (lane == 0) atomicMax(&s_last, need);
     }
     __syncthreads();
     const int kt_last = s_last;
-    const int qlim = p.causal ? qpos : p.T - 1;  // highest visible key position
-    // Q^T operand: 8 consecutive dims per k-slot group, kept in registers for the whole block
-    v8h qreg[4];
-    {
-        const _Float16 *qp = p.qh + ((size_t)h * p.nq_pad + qrow) * kPD + 8 * g;
+    int qlim[NQ];  // highest visible key position of this lane's query in group q
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) qreg[ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
+    for (int q = 0; q < NQ; ++q) qlim[q] = p.causal ? bpos + 16 * q + c : p.T - 1;
+    // Q^T operands: 8 consecutive dims per k-slot group, kept in registers for the whole block
+    v8h qreg[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const _Float16 *qp = p.qh + ((size_t)h * p.nq_pad + qbase + 16 * q + c) * kPD + 8 * g;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) qreg[q][ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
     }
-    v4f o[8];
+    v4f o[NQ][8];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = (v4f){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[q][dt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        m_run[q] = -INFINITY;
+        l_run[q] = 0.0f;
+    }
     const float scale_log2 = 1.4426950408889634f * p.scale;  // softmax in base 2
     const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
     const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
@@ -219,99 +234,133 @@ __global__ __launch_bounds__(NW * 64) void k_prefill_attn(PrefillArgs p) {
     for (int kt = 0; kt <= kt_last; ++kt) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 1024 / NT; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int idx = tid + NT * i;
-            {   // K tile: 64 keys x 128 dims, contiguous 16 KB
-                const int pos = idx >> 4, seg = idx & 15;
-                *reinterpret_cast<uint4 *>(ks + pos * kKPitch + seg * 16) =
-                    *reinterpret_cast<const uint4 *>(kbase + ((size_t)(kt * kQB + pos)) * kPD + seg * 8);
-            }
-            {   // V^T tile: 128 dims x 64 keys
-                const int d = idx >> 3, seg = idx & 7;
-                *reinterpret_cast<uint4 *>(vs + d * kVPitch + seg * 16) =
-                    *reinterpret_cast<const uint4 *>(vbase + (size_t)d * p.Tpad + kt * kQB + seg * 8);
-            }
+            *reinterpret_cast<pv4u *>(ks + (idx >> 4) * kKPitch + (idx & 15) * 16) =
+                *reinterpret_cast<const pv4u *>(kbase + ((size_t)(kt * kQB + (idx >> 4))) * kPD + (idx & 15) * 8);  // K tile: 64 keys x 128 dims
+            *reinterpret_cast<pv4u *>(vs + (idx >> 3) * kVPitch + (idx & 7) * 16) =
+                *reinterpret_cast<const pv4u *>(vbase + (size_t)(idx >> 3) * p.Tpad + kt * kQB + (idx & 7) * 8);    // V^T tile: 128 dims x 64 keys
         }
         __syncthreads();
-        // ---- S^T = K Q^T: 4 key tiles of 16, reduced over 4 dim chunks of 32 ----------------------
-        v4f s[4];
+        // ---- S^T = K Q^T: 4 key tiles of 16, reduced over 4 dim chunks of 32; one operand read per NQ MFMAs ----
+        v4f s[NQ][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
+            for (int i = 0; i < 4; ++i) s[q][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+        {
+            v8h ab[2][4];
+            const uint8_t *kp = ks + c * kKPitch + 16 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const v8h a = *reinterpret_cast<const v8h *>(ks + (16 * i + c) * kKPitch + (32 * ch + 8 * g) * 2);
-                s[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[ch], s[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) ab[0][i] = *reinterpret_cast<const v8h *>(kp + 16 * i * kKPitch);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                if (ch < 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ab[(ch + 1) & 1][i] = *reinterpret_cast<const v8h *>(kp + 16 * i * kKPitch + 64 * (ch + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);  // the reads above stay above these MFMAs
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) s[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[ch & 1][i], qreg[q][ch], s[q][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        // ---- online softmax for query column c (keys of this lane: 16 i + 4 g + j) ---------------
-        float mt = -INFINITY;
+        }
+        // ---- online softmax for query column c of each group (keys of this lane: 16 i + 4 g + j) ----
+        v8h pb[NQ][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < NQ; ++q) {
+            float mt = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pos = kt * kQB + 16 * i + 4 * g + j;
-                const float v = pos <= qlim ? s[i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470) / end of the context
-                s[i][j] = v;
-                mt = fmaxf(mt, v);
-            }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);  // finite: key 0 is visible to every query
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lsum = 0.0f;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = kt * kQB + 16 * i + 4 * g + j;
+                    const float v = pos <= qlim[q] ? s[q][i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470) / end of the context
+                    s[q][i][j] = v;
+                    mt = fmaxf(mt, v);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run[q], mt);  // finite: key 0 is visible to every query
+            const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
+            float lsum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(s[i][j] - m_new);
-                s[i][j] = e;
-                lsum += e;
-            }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
-        // ---- O^T += V^T P^T: k-slot (g, j) = key 32u + 4g + j (j < 4), 32u + 16 + 4g + (j - 4) ------
+                for (int j = 0; j < 4; ++j) {
+                    const float e = __builtin_amdgcn_exp2f(s[q][i][j] - m_new);
+                    s[q][i][j] = e;
+                    lsum += e;
+                }
+            l_run[q] = l_run[q] * alpha + lsum;
+            m_run[q] = m_new;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            v8h pb;
+            for (int dt = 0; dt < 8; ++dt) o[q][dt] *= alpha;
+            // P^T operand: k-slot (g, j) = key 32u + 4g + j (j < 4), 32u + 16 + 4g + (j - 4)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pb[j] = (_Float16)s[2 * u][j];
-                pb[4 + j] = (_Float16)s[2 * u + 1][j];
-            }
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const uint8_t *vp = vs + (16 * dt + c) * kVPitch + (32 * u + 4 * g) * 2;
+                for (int j = 0; j < 4; ++j) {
+                    pb[q][u][j] = (_Float16)s[q][2 * u][j];
+                    pb[q][u][4 + j] = (_Float16)s[q][2 * u + 1][j];
+                }
+        }
+        // ---- O^T += V^T P^T: operand reads four dim tiles ahead ----
+        {
+            v8h vb[2][4];
+            const uint8_t *vp0 = vs + c * kVPitch + 8 * g;
+            auto vread = [&](int u, int dt) {
+                const uint8_t *vp = vp0 + 16 * dt * kVPitch + 64 * u;
                 const v4h lo = *reinterpret_cast<const v4h *>(vp), hi = *reinterpret_cast<const v4h *>(vp + 32);
-                const v8h a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, o[dt], 0, 0, 0);
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[0][i] = vread(0, i);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {  // step = (u, half of the dim tiles)
+                const int u = st >> 1, d0 = 4 * (st & 1);
+                if (st < 3) {
+                    const int un = (st + 1) >> 1, dn = 4 * ((st + 1) & 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) vb[(st + 1) & 1][i] = vread(un, dn + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) o[q][d0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[st & 1][i], pb[q][u], o[q][d0 + i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    l_run += __shfl_xor(l_run, 16);
-    l_run += __shfl_xor(l_run, 32);
-    if (qrow < p.nq) {
-        const float inv = 1.0f / l_run;
-        float *op = p.out + (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            const float4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
-            *reinterpret_cast<float4 *>(op + 16 * dt) = v;
+    for (int q = 0; q < NQ; ++q) {
+        float l = l_run[q];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int qrow = qbase + 16 * q + c;
+        if (qrow < p.nq) {
+            const float inv = 1.0f / l;
+            float *op = p.out + (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const float4 v = {o[q][dt][0] * inv, o[q][dt][1] * inv, o[q][dt][2] * inv, o[q][dt][3] * inv};
+                *reinterpret_cast<float4 *>(op + 16 * dt) = v;
+            }
         }
     }
 }
 
 static void launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
     const int group = p.n_heads / p.n_kv;
-    // 8 waves: 16-wave workgroups (4 heads x 64 queries, half the tile traffic again) measured 5-7 % slower
-    if (group % 4 == 0)
-        hipLaunchKernelGGL((k_prefill_attn<4, 8>), dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4)), dim3(512), 0, stream, p);
-    else if (group % 2 == 0)
-        hipLaunchKernelGGL((k_prefill_attn<2, 8>), dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2)), dim3(512), 0, stream, p);
+    if (group % 4 == 0)  // 4 waves = the 4 heads of a KV head x 32 queries each; two such workgroups per CU
+        hipLaunchKernelGGL((k_prefill_attn<4, 4, 2>), dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4)), dim3(256), 0, stream, p);
+    else if (group % 2 == 0)  // 2 heads x 2 wave columns x 32 queries
+        hipLaunchKernelGGL((k_prefill_attn<2, 4, 2>), dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2)), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((k_prefill_attn<1, 8>), dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((k_prefill_attn<1, 4, 2>), dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads), dim3(256), 0, stream, p);
 }
 
 size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
