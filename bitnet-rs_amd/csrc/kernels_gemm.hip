@@ -206,11 +206,13 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
 // leave most CUs idle in its last round (a 2560-row matrix x 4096 tokens = 320 wide workgroups on 256 CUs).
 typedef unsigned gv4u __attribute__((ext_vector_type(4)));
 
-template <int NDIG, int TTW, int WS, int MINW = 1>
-__global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
+// CW = wave columns: 2 (8 waves, 256 rows x 2 TTW token tiles) or 1 (4 waves, 256 rows x TTW token tiles; with MINW = 2 two such
+// workgroups share a CU with independent barriers at the full register budget).
+template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2>
+__global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
-    constexpr int WG_COLS = 2 * CT * 16;    // plane rows per workgroup
-    constexpr int NB = WG_COLS * 16 / 512;  // uint4 per thread per K step
+    constexpr int WG_COLS = CW * CT * 16;           // plane rows per workgroup
+    constexpr int NB = WG_COLS * 16 / (256 * CW);   // uint4 per thread per K step
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4, rw = wave & 3, cw = wave >> 2;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
     int bdst[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int idx = tid + 512 * i, col = idx >> 4, seg = idx & 15;
+        const int idx = tid + 256 * CW * i, col = idx >> 4, seg = idx & 15;
         bsrc[i] = p.planes + (size_t)(by * WG_COLS + col) * kp + seg * 16;
         bdst[i] = col * kColStride + seg * 16;
     }
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(512, MINW) void k_gemm_mfma(GemmArgs p) {
     // ---- epilogue: digits -> f32, x 2^(E_t - S), [residual | silu*mul], store ------------------
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
-        const int token = (by * 2 * TTW + cw * TTW + tt) * 16 + c;
+        const int token = (by * CW * TTW + cw * TTW + tt) * 16 + c;
         if (token >= p.m) continue;
         const float is = p.inv_scale[token];
         float val[4][4];
@@ -570,26 +572,33 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
     constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
     void (*gk)(GemmArgs) = k32 ? k_gemm_mfma<NDIG, TT32, 3> : !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS;
+    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS, cw = 2;
     const bool scaled_variant = a.wscale || k32;
-    if (NDIG == 2 && !scaled_variant) {
-        // wide tiles: 256 rows x 128 tokens, one workgroup per CU.  When the last round of that grid is mostly empty, the
-        // half-width tiles (two resident per CU) spread the same work evenly
+    // 4-wave workgroups (256 rows x TTW token tiles) bounded to two waves per SIMD: two workgroups share a CU with independent
+    // barriers (one stages its next tile while the other multiplies) at the full register budget, and a 2560-row matrix x
+    // 4096 tokens is 640 workgroups on 512 slots instead of 320 wide ones on 256 CUs.  Measured against the 8-wave tile (and
+    // the spilling 128-register half-width form that used to take the 2560-row launches), 4096 tokens, 2 digits, quantiser
+    // included: gate|up 370 -> 346 us, q|k|v 105 -> 97, o 104 -> 76, down 257 -> 188.
+    static const bool wide8 = getenv("BITNET_HIP_GEMM_WIDE8") && atoi(getenv("BITNET_HIP_GEMM_WIDE8")) == 1;  // the 8-wave forms, for A/B runs
+    if (!wide8 && (!scaled_variant || k32)) {
+        gk = k32 ? k_gemm_mfma<NDIG, TT32, 3, 2, 1> : k_gemm_mfma<NDIG, TTW, 0, 2, 1>;
+        cw = 1;
+    } else if (NDIG == 2 && !scaled_variant) {
         const size_t wide = div_ceil(div_ceil(w.rows, 16), 16) * (size_t)(q.m_pad / 128), rounds = div_ceil(wide, kGemmCUs);
         if ((double)wide / (double)(rounds * kGemmCUs) < 0.8) {
             gk = k_gemm_mfma<2, 2, 0, 4>;
             ttw = 2;
         }
     }
-    const size_t lds = (size_t)2 * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2) + (k32 ? 8 * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
+    const size_t lds = (size_t)cw * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2) + (k32 ? (size_t)4 * cw * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
     static std::unordered_set<const void *> raised;  // once per kernel
     if (!raised.count((const void *)gk)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised.insert((const void *)gk);
     }
-    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (32 * ttw));
-    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(512), lds, stream, a);
+    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
+    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,19 @@
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, '/root/repo')
+pkg = importlib.import_module("bitnet-rs_amd")
+hip = pkg.load(); hip.init(0)
+rng = np.random.default_rng(0)
+for (n, k) in ((13824, 2560), (3840, 2560), (2560, 2560), (2560, 6912)):
+    m = 4096
+    h = hip.weights_upload_qk256(rng.integers(0, 256, n * (k // 256) * 64, dtype=np.uint8), n, k, k // 256 * 64)
+    x = torch.randn(m, k, device="cuda"); y = torch.empty(m, n, device="cuda")
+    wsb = hip.matmul_workspace_bytes(m, k, 2); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    for _ in range(3): hip.matmul_fused_dev(h, x, y, m, ws, wsb, digits=2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): hip.matmul_fused_dev(h, x, y, m, ws, wsb, digits=2)
+    e1.record(); torch.cuda.synchronize()
+    print(f"CW1={os.environ.get('BITNET_HIP_GEMM_CW1','0')}: {n}x{k} m={m}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+    hip.weights_free(h)
