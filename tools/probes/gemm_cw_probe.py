@@ -1,3 +1,4 @@
+"""Developer probe: the tiled matmul on the four 2B-4T shapes, 4096 tokens, 2 digits (BITNET_HIP_GEMM_WIDE8=1: the 8-wave tiles of round 1 for A/B)."""
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, '/root/repo')
@@ -15,5 +16,5 @@ for (n, k) in ((13824, 2560), (3840, 2560), (2560, 2560), (2560, 6912)):
     e0.record()
     for _ in range(20): hip.matmul_fused_dev(h, x, y, m, ws, wsb, digits=2)
     e1.record(); torch.cuda.synchronize()
-    print(f"CW1={os.environ.get('BITNET_HIP_GEMM_CW1','0')}: {n}x{k} m={m}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+    print(f"WIDE8={os.environ.get('BITNET_HIP_GEMM_WIDE8','0')}: {n}x{k} m={m}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
     hip.weights_free(h)
