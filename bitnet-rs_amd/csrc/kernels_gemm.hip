@@ -583,6 +583,14 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     if (!wide8 && (!scaled_variant || k32)) {
         gk = k32 ? k_gemm_mfma<NDIG, TT32, 3, 2, 1> : k_gemm_mfma<NDIG, TTW, 0, 2, 1>;
         cw = 1;
+        if (NDIG == 2 && !scaled_variant) {
+            // few activation rows (a short prompt, or one rank's share of a token-parallel prefill: 1024 rows x 2560 output rows
+            // is 160 of these tiles for 512 slots): narrower token tiles until the grid covers the chip
+            const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
+            while (ttw > 1 && gx0 * (q.m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+            if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
+            if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
+        }
     } else if (NDIG == 2 && !scaled_variant) {
         const size_t wide = div_ceil(div_ceil(w.rows, 16), 16) * (size_t)(q.m_pad / 128), rounds = div_ceil(wide, kGemmCUs);
         if ((double)wide / (double)(rounds * kGemmCUs) < 0.8) {
