@@ -181,6 +181,21 @@ def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
             "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
+def prefill_check(dec, prompt, n: int, digits: int, timed_state):
+    """First-token logits of the TIMED prefill (`--digits`, default 2: the 64-token tile) against the same prompt through the
+    4-digit form (30-bit activations -- the form tests/test_gemm_parity.py and tests/test_bench_prefill_instance.py hold to the
+    oracle's per-row loop within approx_eq_with_len).  Not timed; same weights, same prompt, full model size."""
+    logits_t, token_t = timed_state
+    dec.reset()
+    dec.feed(prompt)
+    dec.prefill(n, with_logits=True, digits=4)
+    b = dec.last_logits().astype(np.float64)
+    token_4 = int(dec.history(n + 1)[n])
+    cos = float(logits_t @ b / (np.linalg.norm(logits_t) * np.linalg.norm(b) + 1e-300))
+    return {"logits_cosine_vs_4_digits": round(cos, 8), "max_abs_diff_over_max_abs": float(np.max(np.abs(logits_t - b)) / (np.max(np.abs(b)) + 1e-300)),
+            "same_first_token": bool(token_t == token_4), "digits_timed": digits, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
+
+
 def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps: int, warmup: int):
     """BASELINE configs[4]: ONE long prompt, token-parallel over the ranks (zigzag chunks, replicated weights, one all-gather
     of the k|v rows per layer; Decoder::prefill_sharded, bitnet-rs_amd/host/decoder.cpp).  The collective is RCCL over xGMI
@@ -213,10 +228,10 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
             gather = tp_mod.torch_gather(r.world)
             how = f"torch.distributed all_gather_into_tensor ({r.backend}, host-synchronised)"
 
-    def one():
+    def one(digits=args.digits):
         dec.reset()
         dec.feed(prompt)
-        dec.prefill_sharded(prompt_len, r.rank, r.world, gather=gather, with_logits=True, digits=args.digits, wire_f16=True,
+        dec.prefill_sharded(prompt_len, r.rank, r.world, gather=gather, with_logits=True, digits=digits, wire_f16=True,
                             rccl_comm=comm.handle if comm else None)
 
     for _ in range(max(1, warmup)):
@@ -230,6 +245,15 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
         dist.all_reduce(t)
         seen = int(t.item())
     token = int(dec.history(prompt_len + 1)[prompt_len]) if r.rank == 0 else -1
+    # not timed: the same prompt through the 4-digit form (every rank takes part: the collective runs again); rank 0 holds the
+    # last prompt position, hence the logits
+    logits_t = dec.last_logits().astype(np.float64) if r.rank == 0 else None
+    one(4)
+    check = None
+    if r.rank == 0:
+        b = dec.last_logits().astype(np.float64)
+        check = {"logits_cosine_vs_4_digits": round(float(logits_t @ b / (np.linalg.norm(logits_t) * np.linalg.norm(b) + 1e-300)), 8),
+                 "same_first_token": bool(token == int(dec.history(prompt_len + 1)[prompt_len])), "digits_timed": args.digits}
     if comm:
         comm.close()
     if r.rank != 0:
@@ -240,6 +264,7 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
         "workload": f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {r.world}xMI355X token-parallel prefill, {prompt_len}-token prompt",
         "tokens": prompt_len, "steps": steps, "ms_per_prompt": round(elapsed / steps * 1e3, 3), "tokens_per_s": round(prompt_len * steps / elapsed, 1),
         "eff_TFLOPs": round(flops * steps / elapsed / 1e12, 1), "digits": args.digits, "ranks_seen": seen, "first_sampled_token": token,
+        "prefill_check": check,
         "parallelism": f"token-parallel x{r.world} (zigzag chunks), weights replicated",
         "collective": f"all-gather of k|v rows (f16 on the wire) per layer: {kv_bytes} B x {cfg.n_layers} layers; {how}" if r.world > 1 else how,
         "scaling": "strong",
@@ -257,6 +282,7 @@ def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
             "dtype": f"i8 MFMA on {args.digits}-digit fixed-point activations (projections), f16 MFMA (attention), f32 accumulate",
             "data": "synthetic", "config": {"workload": res["workload"], "layers": cfg.n_layers, "parallelism": res["parallelism"], "collective": res["collective"]},
             "eff_TFLOPs": res["eff_TFLOPs"], "first_sampled_token": res["first_sampled_token"], "ranks_seen": res["ranks_seen"],
+            "prefill_check": res["prefill_check"],
         }
         print(json.dumps(out), flush=True)
     dec.close()
@@ -330,13 +356,15 @@ def main():
     dec.reset()
     dec.feed(prompt)
     use_graph = not args.eager
-    prefill_ms = None
+    prefill_ms = prefill_tile = prefill_state = None
     if args.workload == "c4":
         # whole-prompt forward (tiled matmuls + causal attention), untimed warm-up pass then the reported one
         dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
         dec.reset()
         dec.feed(prompt)
         prefill_ms = dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
+        prefill_tile = hip.matmul_last_tile()
+        prefill_state = (dec.last_logits().astype(np.float64), int(dec.history(PROMPT_LEN + 1)[PROMPT_LEN]))
     else:
         dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
         dec.run(1, with_logits=True, use_graph=use_graph)                # first sampled token
@@ -385,6 +413,7 @@ def main():
     # outside the timed region: the fast step against the UNFUSED step on the reference-order (bit-exact) kernels, same
     # weights, same short prompt, at the full model size -- a wrong fast kernel cannot hide behind a plausible rate
     check = exact_step_check(dec, synth, cfg)
+    prefill_chk = prefill_check(dec, prompt, PROMPT_LEN, args.digits, prefill_state) if prefill_state is not None else None
     # whole-step view of the same metric: all I2_S matrices of one token / step time
     wb = dec.weight_bytes()
     i2s_gbs = wb / (elapsed / args.steps) / 1e9
@@ -431,7 +460,8 @@ def main():
             flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
             out["prefill"] = {"tokens": PROMPT_LEN, "ms": round(prefill_ms, 2), "tokens_per_s": round(PROMPT_LEN / prefill_ms * 1e3, 1),
                               "digits": args.digits, "eff_TFLOPs": round(flops / prefill_ms / 1e9, 1),
-                              "note": "whole-prompt forward incl. first sampled token; I2_S projections on i8 MFMA digit planes, attention on f16 MFMA"}
+                              "note": "whole-prompt forward incl. first sampled token; I2_S projections on i8 MFMA digit planes, attention on f16 MFMA",
+                              "tile": prefill_tile, "prefill_check": prefill_chk}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
     # N > 1: the decode line above is N independent replicas (batch-1 decode does not shard); the path's ONE real collective
@@ -444,15 +474,18 @@ def main():
         # launcher's own limit).
         import threading
 
-        done = threading.Event()
+        line_lock = threading.Lock()  # the line is printed exactly once: by the timer or by the main thread, whoever gets here first
+        printed = []
 
         def give_up():
-            if done.is_set():
-                return
-            if rank == 0:
-                out["prefill_c5"] = {"error": f"token-parallel prefill did not finish within {args.c5_timeout} s; decode replicas above are unaffected"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            with line_lock:
+                if printed:
+                    return
+                printed.append("timeout")
+                if rank == 0:
+                    out["prefill_c5"] = {"error": f"token-parallel prefill did not finish within {args.c5_timeout} s; decode replicas above are unaffected"}
+                    print(json.dumps(out), flush=True)
+            os._exit(3)  # a hung collective is a FAILED run (the decode line is still on stdout): the launcher must see it
 
         timer = threading.Timer(args.c5_timeout, give_up)
         timer.daemon = True
@@ -464,8 +497,11 @@ def main():
             c5 = sharded_prefill(args, pkg, synth, dist_, r, cfg5, dec5, args.c5_prompt, 2, 1)
         except Exception as e:  # noqa: BLE001 -- reported in the line, not swallowed
             c5 = {"error": f"{type(e).__name__}: {e}"}
-        done.set()
         timer.cancel()
+        with line_lock:
+            if printed:  # the timer fired while the prefill was finishing: its line stands, and so does its exit code
+                os._exit(3)
+            printed.append("main")
     if rank == 0:
         if c5 is not None:
             out["prefill_c5"] = c5

@@ -142,6 +142,7 @@ class HipLib:
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
+        L.bitnet_hip_matmul_last_tile.argtypes = [C.POINTER(C.c_int)] * 4
         L.bitnet_hip_weights_bind_ln.argtypes = [C.c_uint64, _vp, _vp]
         L.bitnet_hip_weights_concat.argtypes = [C.POINTER(C.c_uint64), _sz, C.c_int, C.POINTER(C.c_uint64)]
         L.bitnet_hip_gemv_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, _vp]
@@ -324,6 +325,12 @@ class HipLib:
         self._check(self.c.bitnet_hip_matmul_fused_dev(h, _ptr(x), _ptr(y), m, _ptr(ln_gamma) if ln_gamma is not None else None, ln_eps,
                                                        _ptr(residual) if residual is not None else None, flags, digits, _ptr(workspace),
                                                        workspace_bytes, _vp(stream)))
+
+    def matmul_last_tile(self) -> dict:
+        """The tile form this thread's last tiled matmul ran: {digits, wave_tokens, waves, scale_mode}."""
+        v = [C.c_int() for _ in range(4)]
+        self._check(self.c.bitnet_hip_matmul_last_tile(*[C.byref(x) for x in v]))
+        return dict(zip(("digits", "wave_tokens", "waves", "scale_mode"), (x.value for x in v)))
 
     def attention_prefill_workspace_bytes(self, n_heads: int, n_kv: int, seq_len: int) -> int:
         return int(self.c.bitnet_hip_attention_prefill_workspace_bytes(n_heads, n_kv, seq_len))
@@ -648,6 +655,7 @@ class HostDecoder:
             raise BitNetHipError(ERR_GPU, "bitnet_host_create failed (allocation)")
         err = self.error()
         if err:
+            self.close()  # a dead decoder (rejected configuration, failed allocation) is destroyed before the error is raised
             raise BitNetHipError(ERR_GPU, err)
 
     def error(self) -> str:

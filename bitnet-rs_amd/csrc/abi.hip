@@ -137,10 +137,12 @@ int run_gemv(Weights &w, const float *x_dev, float *y_dev, size_t m, const GemvF
         e = build_tiles(w, stream);  // no-op after the first call (done at upload normally)
         if (e == hipSuccess) e = launch_gemv_mfma(w, x_dev, y_dev, m, fu, stream);
     } else if (kernel == BITNET_HIP_KERNEL_VALU) {
-        e = ensure_reference(w, stream);  // the reference-layout copies are dropped at upload and rebuilt for these kernels
+        ReferencePin pin(w, stream);  // the reference-layout copies are dropped at upload and rebuilt for these kernels
+        e = pin.status;
         if (e == hipSuccess) e = launch_gemv_valu(w, x_dev, y_dev, m, stream);
     } else {
-        e = ensure_reference(w, stream);
+        ReferencePin pin(w, stream);
+        e = pin.status;
         if (e == hipSuccess) e = launch_gemv_exact(w, x_dev, y_dev, m, stream);
     }
     if (e != hipSuccess)
@@ -443,8 +445,11 @@ static int matmul_dev_kernel(bitnet_hip_weights_t h, const float *x_dev, float *
         // released IN STREAM ORDER (no host synchronisation, nothing that outlives the call on the host side);
         // callers that replay the call from a hipGraph pass their own workspace to bitnet_hip_matmul_fused_dev.
         const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
-        if (gemm_needs_row_major_scales(*w) && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
-            return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
+        std::unique_ptr<ReferencePin> pin;  // row-major block scales: held until the launch is enqueued
+        if (gemm_needs_row_major_scales(*w)) {
+            pin.reset(new ReferencePin(*w, (hipStream_t)stream));
+            if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
+        }
         void *ws = nullptr;
         if (hipMallocAsync(&ws, wsb, (hipStream_t)stream) != hipSuccess)
             return set_error(BITNET_HIP_ERR_GPU, "hipMallocAsync failed for the matmul workspace (%zu bytes)", wsb);
@@ -492,12 +497,24 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     const size_t need = gemm_workspace_bytes(m, w->cols, digits);
     if (!workspace_dev || workspace_bytes < need)
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_dev ? workspace_bytes : (size_t)0);
-    if (gemm_needs_row_major_scales(*w) && !w->scales && ensure_reference(*w, (hipStream_t)stream) != hipSuccess)
-        return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
+    std::unique_ptr<ReferencePin> pin;  // row-major block scales: held until the launch is enqueued
+    if (gemm_needs_row_major_scales(*w)) {
+        pin.reset(new ReferencePin(*w, (hipStream_t)stream));
+        if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
+    }
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
     BH_GUARD_END
+}
+
+int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode) {
+    const GemmTileChoice &t = g_last_gemm_tile;
+    if (digits) *digits = t.digits;
+    if (wave_tokens) *wave_tokens = t.wave_tokens;
+    if (waves) *waves = t.waves;
+    if (scale_mode) *scale_mode = t.scale_mode;
+    return t.digits ? BITNET_HIP_OK : set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "no tiled matmul has been launched on this thread");
 }
 
 int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m,
@@ -559,6 +576,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     Weights *f = new Weights();
     *f = *ws[0];
     f->mu = std::make_shared<std::mutex>();
+    f->ref_pins = std::make_shared<std::atomic<int>>(0);
     f->codes = nullptr;
     f->scales = nullptr;
     f->tiles = nullptr;
@@ -624,8 +642,11 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
         return register_weights(f, out);
     }
     // Reference path (odd shapes): the parts' reference layouts are rebuilt if they were dropped
-    for (const WeightsRef &w : ws)
-        if (ensure_reference(*w, nullptr) != hipSuccess) ok = false;
+    std::vector<std::unique_ptr<ReferencePin>> pins;  // the copies below are synchronous: the pins go when this block is left
+    for (const WeightsRef &w : ws) {
+        pins.emplace_back(new ReferencePin(*w, nullptr));
+        if (pins.back()->status != hipSuccess) ok = false;
+    }
     const size_t stride = f->row_stride_bytes, sstride = f->nblk * sizeof(float);
     ok = ok && hipMalloc((void **)&f->codes, rows * stride + 16) == hipSuccess;
     if (ok && f->scaled) ok = hipMalloc((void **)&f->scales, rows * sstride) == hipSuccess;
@@ -647,6 +668,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
             r0 += w->rows;
         }
     }
+    pins.clear();
     for (const WeightsRef &w : ws)
         if (mfma_supported(*w)) trim_reference(*w);
     if (ok && mfma_supported(*f)) ok = build_tiles(*f, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;

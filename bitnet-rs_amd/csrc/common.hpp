@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -64,6 +65,8 @@ struct Weights {
     uint8_t *codes = nullptr;     // [rows, row_stride_bytes] or null
     float *scales = nullptr;      // [rows, nblk] f32 or null (always kept for 256-element blocks: 4 B per 256 weights)
     std::shared_ptr<std::mutex> mu = std::make_shared<std::mutex>();
+    // calls that are about to launch a kernel on `codes` / `scales` (ReferencePin): trim_reference leaves them alone meanwhile
+    std::shared_ptr<std::atomic<int>> ref_pins = std::make_shared<std::atomic<int>>(0);
     size_t algorithmic_bytes = 0; // code bytes + scale bytes
     int device = 0;
     // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
@@ -138,8 +141,21 @@ hipError_t launch_embed_q(const void *table, const int *tokens, const int *offse
 hipError_t build_tiles(Weights &w, hipStream_t stream);
 // codes / scales in the reference layout, rebuilt from the tiles if they were dropped (exact inverse permutation);
 // synchronises `stream` when it had to rebuild.  trim_reference drops them again when the tiles can stand in.
-hipError_t ensure_reference(Weights &w, hipStream_t stream);
+hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin = false);
 void trim_reference(Weights &w);
+// Holds the reference-layout copies from "rebuilt if missing" until the launch that reads them has been ENQUEUED: another thread's
+// trim_reference (bitnet_hip_weights_trim, weights_concat) skips a pinned matrix; once the pin is gone a trim's hipFree waits for
+// the device, so the enqueued kernel still sees its operands (the lock used to be dropped before the launch).
+struct ReferencePin {
+    Weights &w;
+    hipError_t status;
+    ReferencePin(Weights &w_, hipStream_t stream) : w(w_), status(ensure_reference(w_, stream, true)) {}
+    ~ReferencePin() {
+        if (status == hipSuccess) w.ref_pins->fetch_sub(1, std::memory_order_acq_rel);
+    }
+    ReferencePin(const ReferencePin &) = delete;
+    ReferencePin &operator=(const ReferencePin &) = delete;
+};
 size_t weights_device_bytes(const Weights &w);
 // many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
 bool gemm_supported(const Weights &w);
@@ -147,6 +163,12 @@ bool gemm_needs_row_major_scales(const Weights &w);  // 256-block scales and non
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);
 hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
                             void *workspace, size_t workspace_bytes, hipStream_t stream);
+// the tile form launch_gemm_mfma chose on this thread's last call: digits, tokens per wave tile (16 x TTW), waves per workgroup,
+// weight-scale mode (0 none, 1 per 256-block, 2 masked K = 64 per 32-block, 3 K = 32 MFMA with f16 scale tiles)
+struct GemmTileChoice {
+    int digits = 0, wave_tokens = 0, waves = 0, scale_mode = 0;
+};
+extern thread_local GemmTileChoice g_last_gemm_tile;
 extern unsigned long long *g_mfma_stamps;  // diagnostic build only
 hipError_t launch_matmul_i2s_u8(const int8_t *a, const uint8_t *b, float *c, size_t m, size_t n,
                                 size_t k, hipStream_t stream);

@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
 
 // ---- host side ---------------------------------------------------------------------------------
 constexpr size_t kGemmCUs = 256;
+thread_local GemmTileChoice g_last_gemm_tile;  // what the last launch on this thread ran (bitnet_hip_matmul_last_tile)
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -599,12 +600,18 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
         }
     }
     const size_t lds = (size_t)cw * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2) + (k32 ? (size_t)4 * cw * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
-    static std::unordered_set<const void *> raised;  // once per kernel
-    if (!raised.count((const void *)gk)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised.insert((const void *)gk);
+    {
+        // once per kernel; entry points may run concurrently (Send + Sync), so the set is guarded like its twin in kernels_mfma.hip
+        static std::mutex raised_mu;
+        static std::unordered_set<const void *> raised;
+        std::lock_guard<std::mutex> lk(raised_mu);
+        if (!raised.count((const void *)gk)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised.insert((const void *)gk);
+        }
     }
+    g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, 4 * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
     const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
     hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, a);
     return hipGetLastError();

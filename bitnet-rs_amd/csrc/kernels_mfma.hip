@@ -847,6 +847,7 @@ size_t weights_device_bytes(const Weights &w) {
 
 void trim_reference(Weights &w) {
     std::lock_guard<std::mutex> lk(*w.mu);
+    if (w.ref_pins->load(std::memory_order_acquire) > 0) return;  // a launch on the copies is being enqueued (ReferencePin): they stay for now
     if (!w.tiles || w.row_stride_bytes != div_ceil(w.cols, 256) * 64) return;  // only what ensure_reference can rebuild
     if (w.codes) {
         (void)hipFree(w.codes);
@@ -858,24 +859,34 @@ void trim_reference(Weights &w) {
     }
 }
 
-hipError_t ensure_reference(Weights &w, hipStream_t stream) {
+hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin) {
     std::lock_guard<std::mutex> lk(*w.mu);
+    struct PinOnSuccess {  // the pin is taken under the lock, on every successful return
+        Weights &w;
+        bool pin;
+        hipError_t *e;
+        ~PinOnSuccess() {
+            if (pin && *e == hipSuccess) w.ref_pins->fetch_add(1, std::memory_order_acq_rel);
+        }
+    };
+    hipError_t result = hipSuccess;
+    PinOnSuccess guard{w, pin, &result};
     const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
     bool built = false;
     if (!w.codes) {
-        if (!w.tiles) return hipErrorInvalidValue;
+        if (!w.tiles) return result = hipErrorInvalidValue;
         const size_t bytes = w.rows * w.row_stride_bytes + 16;
         hipError_t e = hipMalloc((void **)&w.codes, bytes);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return result = e;
         const size_t total16 = n_tiles * nblk * 64;
         hipLaunchKernelGGL(k_untile, dim3((unsigned)div_ceil(total16, 256)), dim3(256), 0, stream, w.tiles, w.row_stride_bytes, (int)w.rows, (int)nblk,
                            w.codes, total16);
         built = true;
     }
     if (w.scaled && !w.scales) {
-        if (w.block_size != 32 || !(w.scale_tiles || w.scale_tiles_h)) return hipErrorInvalidValue;
+        if (w.block_size != 32 || !(w.scale_tiles || w.scale_tiles_h)) return result = hipErrorInvalidValue;
         hipError_t e = hipMalloc((void **)&w.scales, w.rows * w.nblk * sizeof(float));
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return result = e;
         const size_t total = n_tiles * nblk * 128;
         if (w.scale_tiles_h)
             hipLaunchKernelGGL(k_untile_scales<_Float16>, dim3((unsigned)div_ceil(total, 256)), dim3(256), 0, stream,
@@ -885,10 +896,10 @@ hipError_t ensure_reference(Weights &w, hipStream_t stream) {
                                w.scales, total);
         built = true;
     }
-    if (!built) return hipSuccess;
+    if (!built) return result = hipSuccess;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);  // other threads / streams may use the pointers the moment the lock is gone
-    return e;
+    return result = e;
 }
 
 hipError_t build_tiles(Weights &w, hipStream_t stream) {

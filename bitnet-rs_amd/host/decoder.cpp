@@ -40,6 +40,11 @@ struct Event {  // RAII: an error return between create and destroy must not lea
         if (_rc != 0) return fail(#expr); \
     } while (0)
 
+int Decoder::fail_arg(const char *what) {
+    err_ = what;
+    return BITNET_HIP_ERR_INVALID_ARGUMENT;
+}
+
 int Decoder::fail(const char *what) {
     const char *e = bitnet_hip_get_last_error();
     err_ = std::string(what) + ": " + (e ? e : "error");
@@ -67,6 +72,9 @@ static std::string config_problem(const Config &c) {
 }
 
 Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n_layers <= 4096 ? (size_t)cfg.n_layers : 0) {
+    // A rejected configuration or a failed allocation leaves a DEAD object: error() says why, every other entry point
+    // returns an error without touching a member (c_ used to keep the rejected n_layers while layers_ was empty).
+    dead_ = true;
     err_ = config_problem(cfg);
     if (!err_.empty()) {
         layers_.clear();
@@ -147,6 +155,8 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
     if (hipMemcpy(rope_sin_, sn.data(), sn.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(rope_cos_, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         err_ = "rope table upload failed";
+    if (!err_.empty()) return;
+    dead_ = false;
     reset();
 }
 
@@ -240,7 +250,7 @@ int Decoder::set_act_mode(int mode) {
 }
 
 int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
-    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    if (layer < 0 || (size_t)layer >= layers_.size()) return fail_arg("layer index out of range");
     Layer &L = layers_[(size_t)layer];
     release_layer(L);
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
@@ -261,7 +271,7 @@ int Decoder::set_layer_qk256(int layer, const LayerWeightsQk256 &w) {
 }
 
 int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
-    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    if (layer < 0 || (size_t)layer >= layers_.size()) return fail_arg("layer index out of range");
     Layer &L = layers_[(size_t)layer];
     release_layer(L);
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
@@ -281,7 +291,7 @@ int Decoder::set_layer_i2s(int layer, const LayerWeightsI2s &w) {
 }
 
 int Decoder::set_layer_specs(int layer, const float *attn_norm, const float *ffn_norm, const ProjSpec p[7]) {
-    if (layer < 0 || layer >= c_.n_layers) return fail("layer index out of range");
+    if (layer < 0 || (size_t)layer >= layers_.size()) return fail_arg("layer index out of range");
     Layer &L = layers_[(size_t)layer];
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, KD = (size_t)c_.n_kv_heads * c_.head_dim, F = c_.ffn;
     const size_t n[7] = {QD, KD, KD, H, F, F, H}, k[7] = {H, H, H, QD, H, H, F};
@@ -598,6 +608,10 @@ int Decoder::run_reference(int n, bool with_logits) {
         if (rc) return rc;
     }
     HCHK(hipStreamSynchronize((hipStream_t)stream_));
+    // the reference-order kernels rebuilt a row-major copy of every matrix: give them back (one copy of the weights on the device)
+    for (auto &L : layers_)
+        for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down})
+            if (h) bitnet_hip_weights_trim(h);
     return 0;
 }
 
@@ -912,6 +926,10 @@ int Decoder::finish_prefill(int n, const float *last_row, bool with_logits) {
 }
 
 void Decoder::layer_objects(int layer, uint64_t handles[4], void *ptrs[4]) const {
+    if (layer < 0 || (size_t)layer >= layers_.size()) {
+        for (int i = 0; i < 4; ++i) handles[i] = 0, ptrs[i] = nullptr;
+        return;
+    }
     const Layer &L = layers_[(size_t)layer];
     handles[0] = L.qkv, handles[1] = L.o, handles[2] = L.gateup, handles[3] = L.down;
     ptrs[0] = L.attn_norm, ptrs[1] = L.ffn_norm, ptrs[2] = L.kcache, ptrs[3] = L.vcache;
@@ -1042,6 +1060,17 @@ int Decoder::probe_gateup(int reps, float *us_per_launch, double *bytes_per_laun
 
 using bitnet_host::Decoder;
 
+namespace {
+// a null handle or a dead decoder (rejected configuration, failed allocation): nothing but error() / destroy may be called
+inline Decoder *live(void *d) {
+    Decoder *p = static_cast<Decoder *>(d);
+    return p && !p->dead() ? p : nullptr;
+}
+}  // namespace
+#define LIVE(rc)           \
+    Decoder *D = live(d);  \
+    if (!D) return rc
+
 extern "C" {
 void *bitnet_host_create(const bitnet_host_config *cfg) {
     bitnet_host::Config c;
@@ -1064,12 +1093,13 @@ void *bitnet_host_create(const bitnet_host_config *cfg) {
     }
 }
 void bitnet_host_destroy(void *d) { delete static_cast<Decoder *>(d); }
-const char *bitnet_host_error(void *d) { return static_cast<Decoder *>(d)->error().c_str(); }
+const char *bitnet_host_error(void *d) { return d ? static_cast<Decoder *>(d)->error().c_str() : "null decoder"; }
 int bitnet_host_set_layer_qk256(void *d, int layer, const float *attn_norm, const float *ffn_norm, const uint8_t *q,
                                 const uint8_t *k, const uint8_t *v, const uint8_t *o, const uint8_t *gate,
                                 const uint8_t *up, const uint8_t *down) {
     bitnet_host::LayerWeightsQk256 w{attn_norm, ffn_norm, q, k, v, o, gate, up, down};
-    return static_cast<Decoder *>(d)->set_layer_qk256(layer, w);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->set_layer_qk256(layer, w);
 }
 int bitnet_host_set_layer_i2s(void *d, int layer, const float *attn_norm, const float *ffn_norm, const uint8_t *const *w7,
                               const float *const *scales7, size_t block_size) {
@@ -1081,27 +1111,32 @@ int bitnet_host_set_layer_i2s(void *d, int layer, const float *attn_norm, const 
         w.scales[i] = scales7[i];
     }
     w.block_size = block_size;
-    return static_cast<Decoder *>(d)->set_layer_i2s(layer, w);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->set_layer_i2s(layer, w);
 }
 int bitnet_host_set_globals(void *d, const uint16_t *embed_f16, const float *final_norm) {
-    return static_cast<Decoder *>(d)->set_globals(embed_f16, final_norm);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->set_globals(embed_f16, final_norm);
 }
-int bitnet_host_reset(void *d) { return static_cast<Decoder *>(d)->reset(); }
-int bitnet_host_feed(void *d, const int32_t *tokens, int n) { return static_cast<Decoder *>(d)->feed(tokens, n); }
-int bitnet_host_set_kv_f16(void *d, int on) { return static_cast<Decoder *>(d)->set_kv_f16(on != 0); }
-int bitnet_host_set_act_mode(void *d, int mode) { return static_cast<Decoder *>(d)->set_act_mode(mode); }
-int bitnet_host_act_mode(void *d) { return static_cast<Decoder *>(d)->qact_path() ? 1 : 0; }
-int bitnet_host_prepare_graphs(void *d, int with_logits) { return static_cast<Decoder *>(d)->prepare_graphs(with_logits != 0); }
-int bitnet_host_run_reference(void *d, int n, int with_logits) { return static_cast<Decoder *>(d)->run_reference(n, with_logits != 0); }
+int bitnet_host_reset(void *d) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->reset(); }
+int bitnet_host_feed(void *d, const int32_t *tokens, int n) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->feed(tokens, n); }
+int bitnet_host_set_kv_f16(void *d, int on) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->set_kv_f16(on != 0); }
+int bitnet_host_set_act_mode(void *d, int mode) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->set_act_mode(mode); }
+int bitnet_host_act_mode(void *d) { LIVE(0); return D->qact_path() ? 1 : 0; }
+int bitnet_host_prepare_graphs(void *d, int with_logits) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->prepare_graphs(with_logits != 0); }
+int bitnet_host_run_reference(void *d, int n, int with_logits) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->run_reference(n, with_logits != 0); }
 int bitnet_host_run(void *d, int n, int with_logits, int use_graph, float *elapsed_ms) {
-    return static_cast<Decoder *>(d)->run(n, with_logits != 0, use_graph != 0, elapsed_ms);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->run(n, with_logits != 0, use_graph != 0, elapsed_ms);
 }
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms) {
-    return static_cast<Decoder *>(d)->prefill(n, with_logits != 0, digits, elapsed_ms);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->prefill(n, with_logits != 0, digits, elapsed_ms);
 }
 int bitnet_host_prefill_sharded(void *d, int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, int with_logits,
                                 int digits, int wire_f16, float *elapsed_ms) {
-    return static_cast<Decoder *>(d)->prefill_sharded(n, rank, world, gather, gather_ctx, with_logits != 0, digits, wire_f16 != 0, elapsed_ms);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->prefill_sharded(n, rank, world, gather, gather_ctx, with_logits != 0, digits, wire_f16 != 0, elapsed_ms);
 }
 int bitnet_host_rccl_allgather(void *nccl_comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream) {
     // ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
@@ -1115,26 +1150,35 @@ int bitnet_host_rccl_allgather(void *nccl_comm, const void *send_dev, void *recv
     return fn(send_dev, recv_dev, bytes_per_rank, /* ncclUint8 */ 1, nccl_comm, stream);
 }
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits) {
-    return static_cast<Decoder *>(d)->finish_prefill(n, last_row, with_logits != 0);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->finish_prefill(n, last_row, with_logits != 0);
 }
-void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4) { static_cast<Decoder *>(d)->layer_objects(layer, handles4, ptrs4); }
-void bitnet_host_global_objects(void *d, void **ptrs7) { static_cast<Decoder *>(d)->global_objects(ptrs7); }
-int bitnet_host_position(void *d) { return static_cast<Decoder *>(d)->position(); }
-int bitnet_host_history(void *d, int32_t *out, int n) { return static_cast<Decoder *>(d)->history(out, n); }
-int bitnet_host_last_logits(void *d, float *out) { return static_cast<Decoder *>(d)->last_logits(out); }
-int bitnet_host_last_hidden(void *d, float *out) { return static_cast<Decoder *>(d)->last_hidden(out); }
+void bitnet_host_layer_objects(void *d, int layer, uint64_t *handles4, void **ptrs4) {
+    for (int i = 0; i < 4; ++i) handles4[i] = 0, ptrs4[i] = nullptr;
+    if (Decoder *D = live(d)) D->layer_objects(layer, handles4, ptrs4);
+}
+void bitnet_host_global_objects(void *d, void **ptrs7) {
+    for (int i = 0; i < 7; ++i) ptrs7[i] = nullptr;
+    if (Decoder *D = live(d)) D->global_objects(ptrs7);
+}
+int bitnet_host_position(void *d) { LIVE(-1); return D->position(); }
+int bitnet_host_history(void *d, int32_t *out, int n) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->history(out, n); }
+int bitnet_host_last_logits(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_logits(out); }
+int bitnet_host_last_hidden(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_hidden(out); }
 int bitnet_host_blake3_hex(const void *data, size_t len, char *out65) {
     if (!out65 || (!data && len)) return -1;
     const std::string h = bitnet_host::Blake3::hex(data, len);
     memcpy(out65, h.c_str(), 65);
     return 0;
 }
-int bitnet_host_trace_step(void *d, const char *dir, int with_logits) { return static_cast<Decoder *>(d)->trace_step(dir, with_logits != 0); }
+int bitnet_host_trace_step(void *d, const char *dir, int with_logits) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->trace_step(dir, with_logits != 0); }
 int bitnet_host_probe_gateup(void *d, int reps, float *us_per_launch, double *bytes_per_launch) {
-    return static_cast<Decoder *>(d)->probe_gateup(reps, us_per_launch, bytes_per_launch);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->probe_gateup(reps, us_per_launch, bytes_per_launch);
 }
 int bitnet_host_probe_kernel(void *d, int kind, int reps, float *us_per_launch, double *bytes_per_launch) {
-    return static_cast<Decoder *>(d)->probe_kernel(kind, reps, us_per_launch, bytes_per_launch);
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    return D->probe_kernel(kind, reps, us_per_launch, bytes_per_launch);
 }
-uint64_t bitnet_host_weight_bytes(void *d) { return static_cast<Decoder *>(d)->weight_bytes(); }
+uint64_t bitnet_host_weight_bytes(void *d) { LIVE(0); return D->weight_bytes(); }
 }

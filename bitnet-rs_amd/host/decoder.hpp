@@ -68,6 +68,7 @@ class Decoder {
 
     const Config &config() const { return c_; }
     const std::string &error() const { return err_; }
+    bool dead() const { return dead_; }  // construction failed: only error() and the destructor may be used
     void set_error(const std::string &e) { err_ = e; }
 
     // weights (uploaded once; fused q|k|v and interleaved gate/up handles are built here)
@@ -139,6 +140,8 @@ class Decoder {
 
   private:
     int fail(const char *what);
+    int fail_arg(const char *what);
+    bool dead_ = false;
     // attention form of a step: 0 = two kernels, 64-position chunks; 1 = one kernel + merging o-projection (short
     // contexts); 2 = two kernels, 128-position chunks (more chunks than CUs)
     struct Tracer;

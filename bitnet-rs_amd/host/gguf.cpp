@@ -778,7 +778,7 @@ int bitnet_host_gguf_check_projection(void *gp, int64_t idx, uint64_t rows, uint
     return 0;
 }
 int bitnet_host_load_gguf(void *decoder, void *g) {
-    if (!decoder || !g) return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    if (!decoder || !g || static_cast<Decoder *>(decoder)->dead()) return BITNET_HIP_ERR_INVALID_ARGUMENT;
     return load_gguf_into(*static_cast<Decoder *>(decoder), *static_cast<GgufFile *>(g));
 }
 }

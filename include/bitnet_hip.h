@@ -220,6 +220,11 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
                                 int flags, int digits, void *workspace_dev, size_t workspace_bytes,
                                 void *stream);
+/* Which tile form the calling thread's last bitnet_hip_matmul_[fused_]dev launch ran (any pointer may be null): digits,
+ * tokens per wave tile (16 / 32 / 64), waves per workgroup (4 / 8), weight-scale mode (0 none, 1 per 256-block, 2 per
+ * 32-block on the masked K = 64 MFMA, 3 per 32-block on the K = 32 MFMA with f16 scale tiles).  The parity tests assert
+ * that the instance bench.py times (2 digits, 64-token tile) is the one they compared with the oracle. */
+int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode);
 
 /* Several uploaded matrices with the same cols / code map / block size as ONE
  * launch: rows concatenated (q|k|v share their input: T:288-290).  interleave16 != 0

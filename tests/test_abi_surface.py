@@ -135,3 +135,41 @@ def test_new_entry_points_validate_arguments_without_a_gpu(lib):
     c.bitnet_hip_attention_decode_partial_dev.argtypes = [C.c_void_p] * 5 + [C.c_size_t] * 4 + [C.c_void_p] * 3
     assert c.bitnet_hip_attention_decode_partial_dev(None, None, None, None, None, 8, 2, 128, 512, None, None, None) != 0
     assert b"Null pointer" in c.bitnet_hip_get_last_error()
+
+
+def test_rejected_config_gives_a_dead_decoder_that_refuses_every_call(pkg):
+    """a configuration the kernels cannot take (here hidden % 512 != 0, as untrusted GGUF metadata could say)
+    used to leave an object whose layer table was empty while its layer count was not -- set_layer_* indexed past it.
+    Now the object is dead: error() says why, every other entry returns an error, nothing is dereferenced."""
+    import ctypes as C
+
+    c = C.CDLL(pkg.HOST_LIB_PATH)
+    c.bitnet_host_create.restype = C.c_void_p
+    c.bitnet_host_create.argtypes = [C.POINTER(pkg.HostConfig)]
+    c.bitnet_host_error.restype = C.c_char_p
+    c.bitnet_host_error.argtypes = [C.c_void_p]
+    hc = pkg.HostConfig(hidden=100, n_layers=4, n_heads=4, n_kv_heads=2, head_dim=128, ffn=256, vocab=64, max_pos=32, eps=1e-5, rope_theta=1e4)
+    d = c.bitnet_host_create(C.byref(hc))
+    assert d and b"multiple of 512" in c.bitnet_host_error(d)
+    fl = (C.c_float * 128)()
+    u8 = (C.c_uint8 * 128)()
+    c.bitnet_host_set_layer_qk256.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    for layer in (0, 3, -1, 1 << 20):
+        assert c.bitnet_host_set_layer_qk256(d, layer, fl, fl, u8, u8, u8, u8, u8, u8, u8) != 0
+    for name in ("bitnet_host_reset", "bitnet_host_position"):
+        getattr(c, name).argtypes = [C.c_void_p]
+        assert getattr(c, name)(d) != 0
+    c.bitnet_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    assert c.bitnet_host_run(d, 1, 1, 0, None) != 0
+    c.bitnet_host_layer_objects.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    hs, ps = (C.c_uint64 * 4)(1, 1, 1, 1), (C.c_void_p * 4)()
+    c.bitnet_host_layer_objects(d, 0, hs, ps)
+    assert list(hs) == [0, 0, 0, 0]
+    c.bitnet_host_destroy.argtypes = [C.c_void_p]
+    c.bitnet_host_destroy(d)
+    # the Python wrapper raises and does not leak the object
+    import importlib
+
+    synth = importlib.import_module("bitnet-rs_amd.synth")
+    with pytest.raises(pkg.BitNetHipError, match="multiple of 512"):
+        pkg.HostDecoder(synth.ModelConfig(hidden=100, n_layers=1, n_heads=4, n_kv_heads=2, head_dim=128, ffn=256, vocab=64, max_pos=32))

@@ -1,0 +1,201 @@
+"""The prefill instances bench.py TIMES (c4 / c5: `--digits 2`, 4096+ tokens at the bitnet-b1.58-2B-4T widths) against the
+CPU oracle -- VERDICT r02 "what's weak" 1: the small 2-digit tests collapse the launcher's token tile to 16 / 32 tokens, a
+different template instantiation from the 64-token tile `k_gemm_mfma<2, 4, 0, 2, 1>` the 25 ms number runs on.
+
+  (a) every projection shape of the model x 4096 token rows x 2 digits, QK256 (64-token tile, K = 64 MFMA) and BitNet32-F16
+      (32-token tile, K = 32 MFMA + f16 scale tiles), with the fusions the prefill loop uses (LayerNorm prologue, silu*mul,
+      residual); the launcher's choice is read back through bitnet_hip_matmul_last_tile and asserted; the oracle
+      (gemv_qk256 Q/i2s_qk256.rs:196-321 per row as forward_qk256 does T:683-691; i2s_matmul_f32
+      K/cpu/quantized_matmul.rs:57-96) runs on a sample of token rows, all output rows of them.
+      Gate: cosine >= 0.99999 per row (benches/qk256_gemv.rs:234) and max |diff| <= 2e-4 * max |want| (16-bit activations).
+  (b) whole prompt prefill(digits = 2) -> decode against the oracle's token-by-token model on the 2-layer model of the 2B-4T
+      widths, 1024 tokens (the gate|up launch takes the wide tile there), both formats; plus the 4096-token prompt, where
+      EVERY launch takes the wide tile, against the 4-digit prefill that (a) and test_prefill_parity pin to the oracle."""
+import importlib
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M = 4096
+SAMPLE = 64
+WIDE = dict(hidden=2560, n_layers=2, n_heads=20, n_kv_heads=5, head_dim=128, ffn=6912, vocab=4096, max_pos=4224, eps=1e-5, rope_theta=500000.0)
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def synth(pkg):
+    return importlib.import_module("bitnet-rs_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+
+    return torch
+
+
+@pytest.fixture(scope="module")
+def layers(synth):
+    cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
+    return cfg, {"qk256": synth.make_layer(cfg, 0, fmt="qk256"), "i2s": synth.make_layer(cfg, 0, fmt="i2s", block=32)}
+
+
+def upload(hip, lay, fmt, name, rows, cols):
+    if fmt == "qk256":
+        return hip.weights_upload_qk256(lay[name], rows, cols, cols // 256 * 64)
+    return hip.weights_upload_i2s(lay[name], lay[name + "_scales"], rows, cols, 32)
+
+
+def oracle_rows(oracle, lay, fmt, name, rows, cols, xs):
+    """W x for every sampled row: the reference's own per-row loop (QK256) / i2s_matmul_f32 (ternary x block scale)."""
+    if fmt == "qk256":
+        return np.stack([oracle.gemv_qk256(lay[name], xs[i], rows, cols, cols // 256 * 64) for i in range(xs.shape[0])])
+    return oracle.i2s_matmul(xs.reshape(-1), lay[name], lay[name + "_scales"], xs.shape[0], rows, cols, 32).reshape(xs.shape[0], rows)
+
+
+EXPECT_TILE = {"qk256": dict(digits=2, wave_tokens=64, waves=4, scale_mode=0), "i2s": dict(digits=2, wave_tokens=32, waves=4, scale_mode=3)}
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+@pytest.mark.parametrize("case", ["qkv_ln", "o_residual", "gateup_ln_silu", "down_residual"])
+def test_benchmarked_tile_matches_oracle(hip, oracle, torch_, layers, fmt, case):
+    cfg, both = layers
+    lay = both[fmt]
+    H, F, QD, KD = cfg.hidden, cfg.ffn, cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+    rng = np.random.default_rng(zlib.crc32(f"{fmt}/{case}".encode()))
+    sample = np.sort(rng.choice(M, SAMPLE, replace=False))
+    sample[0], sample[-1] = 0, M - 1  # first and last row of the launch
+    if case == "qkv_ln":
+        names, K, gamma = ("q", "k", "v"), H, lay["attn_norm"]
+    elif case == "gateup_ln_silu":
+        names, K, gamma = ("gate", "up"), H, lay["ffn_norm"]
+    elif case == "o_residual":
+        names, K, gamma = ("o",), QD, None
+    else:
+        names, K, gamma = ("down",), F, None
+    shapes = cfg.shapes()
+    parts = [upload(hip, lay, fmt, n, *shapes[n]) for n in names]
+    if len(parts) == 1:
+        h = parts[0]
+    else:
+        h = hip.weights_concat(parts, interleave16=(case == "gateup_ln_silu"))
+        for p in parts:
+            hip.weights_free(p)
+    # activations: per-row magnitudes over three decades (the fixed-point scale is per row), a non-zero mean for LayerNorm
+    x = rng.normal(0.2 if gamma is not None else 0.0, 1.0, (M, K)).astype(np.float32)
+    x *= np.exp(rng.uniform(np.log(0.05), np.log(50.0), (M, 1))).astype(np.float32)
+    out_cols = F if case == "gateup_ln_silu" else sum(shapes[n][0] for n in names)
+    res = rng.normal(0, 1, (M, out_cols)).astype(np.float32) if gamma is None else None
+    wsb = hip.matmul_workspace_bytes(M, K, 4)  # sized for the 4-digit pass below; the 2-digit one needs less
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    xd = torch_.from_numpy(x).cuda()
+    yd = torch_.full((M, out_cols), float("nan"), device="cuda")
+    gd = torch_.from_numpy(gamma).cuda() if gamma is not None else None
+    rd = torch_.from_numpy(res).cuda() if res is not None else None
+    hip.matmul_fused_dev(h, xd, yd, M, ws, wsb, ln_gamma=gd, ln_eps=cfg.eps if gamma is not None else 0.0, residual=rd,
+                         flags=1 if case == "gateup_ln_silu" else 0, digits=2)
+    torch_.cuda.synchronize()
+    assert hip.matmul_last_tile() == EXPECT_TILE[fmt], hip.matmul_last_tile()  # the instance bench.py's c4 / c5 prefill runs
+    got_all = yd.cpu().numpy()
+    assert not np.isnan(got_all).any()
+    got = got_all[sample]
+    xs = x[sample]
+    if gamma is not None:
+        xs = np.stack([oracle.layernorm(xs[i], gamma, cfg.eps) for i in range(SAMPLE)])
+    ys = [oracle_rows(oracle, lay, fmt, n, *shapes[n], xs) for n in names]
+    if case == "gateup_ln_silu":
+        g, u = ys
+        want = (g / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32) * u  # T:756-781
+        prod = want
+    else:
+        prod = np.concatenate(ys, axis=1)
+        want = prod + (res[sample] if res is not None else 0.0)
+    # per sampled row: the product's own scale bounds the error (a residual of another magnitude must not loosen the gate)
+    for i in range(SAMPLE):
+        err = np.max(np.abs(got[i] - want[i]))
+        assert err <= 2e-4 * np.max(np.abs(prod[i])) + 1e-6, (fmt, case, int(sample[i]), err, np.max(np.abs(prod[i])))
+        gp = got[i] - (res[sample[i]] if res is not None else 0.0)
+        assert cosine(gp, prod[i]) >= 0.99999, (fmt, case, int(sample[i]))
+    # 4 digits (the oracle-pinned form of tests/test_gemm_parity.py) over ALL 4096 rows bounds what 2 digits may differ by:
+    # 2^-14 of the row maximum per element, |w| <= 2 (QK256) or <= max scale (ternary)
+    hip.matmul_fused_dev(h, xd, yd, M, ws, wsb, ln_gamma=gd, ln_eps=cfg.eps if gamma is not None else 0.0, residual=rd,
+                         flags=1 if case == "gateup_ln_silu" else 0, digits=4)
+    torch_.cuda.synchronize()
+    y4 = yd.cpu().numpy()
+    if res is not None:
+        got_all, y4 = got_all - res, y4 - res
+    scale = np.max(np.abs(y4), axis=1, keepdims=True)
+    assert np.all(np.abs(got_all - y4) <= 4e-4 * scale + 1e-6), float(np.max(np.abs(got_all - y4) / (scale + 1e-30)))
+    hip.weights_free(h)
+
+
+def _models(synth, fmt, cfg):
+    glob = synth.make_globals(cfg)
+    if fmt == "qk256":
+        layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+        return glob, layers, layers
+    layers = [synth.make_layer(cfg, l, fmt="i2s", block=32) for l in range(cfg.n_layers)]
+    tmap = np.array([0, 1, 0, -1], np.float32)
+    olayers = []
+    for lay in layers:
+        d = {"attn_norm": lay["attn_norm"], "ffn_norm": lay["ffn_norm"], "dense": True}
+        for name, (rows, cols) in cfg.shapes().items():
+            pk = lay[name].reshape(rows, cols // 4)
+            codes = np.stack([(pk >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(rows, cols)
+            d[name] = tmap[codes] * np.repeat(lay[name + "_scales"].reshape(rows, cols // 32), 32, axis=1)
+        olayers.append(d)
+    return glob, layers, olayers
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle, synth, fmt):
+    cfg = synth.ModelConfig(**WIDE)
+    glob, layers, olayers = _models(synth, fmt, cfg)
+    n_prompt, n_new = 1024, 3
+    prompt = synth.prompt(4096, cfg.vocab)
+    om = oracle.OracleModel(cfg, olayers, glob, n_threads=16)
+    seq = list(prompt[:n_prompt])
+    o_logits = []
+    for p in range(n_prompt + n_new - 1):
+        _, logits, _ = om.step(seq[p], want_logits=p >= n_prompt - 1)
+        if p >= n_prompt - 1:
+            o_logits.append(logits)
+            seq.append(oracle.argmax(logits))
+    om.close()
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_qk256(l, w) if fmt == "qk256" else dec.set_layer_i2s(l, w, 32)
+    dec.set_globals(glob)
+    dec.reset()
+    dec.feed(prompt[:n_prompt])
+    dec.prefill(n_prompt, with_logits=True, digits=2)
+    t = hip.matmul_last_tile()  # the last launch of the loop is a 2560-row down-projection: narrower tile at 1024 rows (QK256)
+    assert t["digits"] == 2 and t["scale_mode"] == (0 if fmt == "qk256" else 3)
+    assert dec.position() == n_prompt
+    c = cosine(dec.last_logits(), o_logits[0])
+    assert c >= 0.9999, c
+    for i in range(1, n_new):
+        dec.run(1, with_logits=True, use_graph=True)
+        c = cosine(dec.last_logits(), o_logits[i])
+        assert c >= 0.9999, (i, c)
+    assert list(dec.history(n_prompt + n_new)) == [int(t) for t in seq]
+    # 4096 tokens: every launch takes the benchmarked tile; against the oracle-pinned 4-digit prefill of the same prompt
+    out = {}
+    for digits in (4, 2):
+        dec.reset()
+        dec.feed(prompt)
+        dec.prefill(4096, with_logits=True, digits=digits)
+        tile = hip.matmul_last_tile()
+        out[digits] = (dec.last_logits().copy(), int(dec.history(4097)[4096]), dec.last_hidden().copy())
+    assert tile == EXPECT_TILE[fmt], tile
+    assert cosine(out[2][0], out[4][0]) >= 0.9999
+    assert cosine(out[2][2], out[4][2]) >= 0.9999
+    assert out[2][1] == out[4][1]
+    dec.close()
