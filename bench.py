@@ -181,6 +181,73 @@ def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
             "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
+def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int = 12, launches: int | None = None):
+    """The decode GEMV's STREAMING rate: the very kernel instance of the fused gate|up launch (k_gemv_q<8, 5, SC, LN, 1>: LayerNorm
+    after the product, silu*mul, QAct in and out) over ONE matrix of `layers_worth` gate|up matrices laid end to end -- 64 x
+    13824 rows x 2560 columns = 566 MB of 2-bit codes (+ 142 MB of f16 block scales for BitNet32-F16), larger than every cache
+    of the chip (MALL 256 MiB), so each launch streams its bytes from HBM and the per-launch fixed costs of the decode chain
+    (one 11 MB burst per launch) are amortised.  HIP events on the launch stream around `reps` back-to-back launches.
+    This is the regime north_star's ">= 60 % of the HBM-read roofline on the I2_S ternary matmul" can be read in."""
+    import torch
+
+    cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
+    K, F = cfg.hidden, cfg.ffn * layers_worth
+    if fmt == "i2s":
+        g, gs = synth.ternary_weights(F, K, 32, 42, 1000, 4)
+        u, us = synth.ternary_weights(F, K, 32, 42, 1000, 5)
+        hg, hu = hip.weights_upload_i2s(g, gs, F, K, 32), hip.weights_upload_i2s(u, us, F, K, 32)
+        del g, gs, u, us
+    else:
+        stride = K // 256 * 64
+        hg = hip.weights_upload_qk256(synth.qk256_codes(F, K, 42, 1000, 4), F, K, stride)
+        hu = hip.weights_upload_qk256(synth.qk256_codes(F, K, 42, 1000, 5), F, K, stride)
+    h = hip.weights_concat([hg, hu], interleave16=True)
+    hip.weights_free(hg)
+    hip.weights_free(hu)
+    rng = np.random.default_rng(5)
+    gamma = torch.from_numpy((rng.uniform(0.5, 1.5, K) / 80).astype(np.float32)).cuda()
+    hip.weights_bind_ln(h, gamma)
+    x = torch.from_numpy(rng.normal(0.1, 1.0, K).astype(np.float32)).cuda()
+    qa = torch.zeros(hip.qact_bytes(K), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(hip.qact_stats_bytes(K), dtype=torch.uint8, device="cuda")
+    hip.quantize_act_dev(x, gamma, K, qa, st)
+    qo = torch.zeros(hip.qact_bytes(F), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def launch():
+        hip.gemv_q_dev(h, qa, None, st, gamma, cfg.eps, None, 1, qo, None, None, stream=stream.cuda_stream)
+
+    launch()  # warm-up (code object, instruction cache)
+    stream.synchronize()
+    if launches is not None:  # profiler passes: a fixed, small number of dispatches
+        for _ in range(launches):
+            launch()
+        stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(3 if launches is None else 0):
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        stream.synchronize()
+        us_launch = e0.elapsed_time(e1) * 1e3 / reps
+        best = us_launch if best is None or us_launch < best else best
+    _, _, wbytes = hip.weights_info(h)
+    # algorithmic bytes of one launch (SURVEY 8d): codes + scales, QAct records + statistics pairs in, g_r per stored row, QAct out
+    abytes = wbytes + hip.qact_bytes(K) + hip.qact_stats_bytes(K) + 8 * F + hip.qact_bytes(F)
+    hip.weights_free(h)
+    out = {"kernel": "k_gemv_q (the decode step's fused LayerNorm -> gate|up GEMV -> silu*mul instance, one launch over the whole matrix)",
+           "format": "BitNet32-F16" if fmt == "i2s" else "QK256", "rows": 2 * F, "cols": K, "bytes_per_launch": int(abytes)}
+    if best is not None:
+        gbs = abytes / best / 1e3
+        out.update({"us_per_launch": round(best, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "launches_timed": reps, "timing": "HIP events on the launch stream, best of 3 bursts",
+                    "traffic": load_traffic("stream_" + fmt)})
+    return out
+
+
 def prefill_check(dec, prompt, n: int, digits: int, timed_state):
     """First-token logits of the TIMED prefill (`--digits`, default 2: the 64-token tile) against the same prompt through the
     4-digit form (30-bit activations -- the form tests/test_gemm_parity.py and tests/test_bench_prefill_instance.py hold to the
@@ -294,7 +361,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "stream"])
+    ap.add_argument("--stream-layers", type=int, default=64, help="i2s_stream: gate|up matrices laid end to end (64 = 708 MB BitNet32-F16 / 566 MB QK256)")
+    ap.add_argument("--stream-launches", type=int, default=None, help="stream workload only: a fixed number of launches and no timing (profiler counter passes)")
+    ap.add_argument("--stream-format", default="i2s", choices=["i2s", "qk256"])
+    ap.add_argument("--no-stream", action="store_true", help="skip the i2s_stream object of the default line")
     ap.add_argument("--prompt", type=int, default=None, help="prompt length (default 128; 4096 for c4)")
     ap.add_argument("--digits", type=int, default=2, help="c4 / c5 prefill: fixed-point digits per activation row in the tiled matmuls (2: 15 bits of the row "
                     "maximum, the f16-class activation north_star names; measured end to end at 4096 tokens x 30 layers: logits cosine 0.999996 vs 4 digits, "
@@ -343,6 +414,14 @@ def main():
 
     global PROMPT_LEN
     PROMPT_LEN = args.prompt or {"c4": 4096, "c5": 8192}.get(args.workload, 128)
+    if args.workload == "stream":  # the streaming-rate probe alone (tools/profile_round.sh runs its counter passes through this)
+        res = i2s_stream(hip, synth, args.stream_format, args.stream_layers, launches=args.stream_launches)
+        if rank == 0:
+            print(json.dumps({"metric": "I2_S matmul HBM GB/s (% roofline), streaming regime", "value": res.get("achieved"), "unit": "GB/s", "n_gpus": n_gpus,
+                              "steps": res.get("launches_timed"), "warmup": 1, "higher_is_better": True, "vs_baseline": None, "dtype": "i8 MFMA on QAct",
+                              "data": "synthetic", "config": {"workload": f"k_gemv_q over {res['rows']} x {res['cols']} {res['format']}"}, "i2s_stream": res}), flush=True)
+        dist_.finalize(r)
+        return
     gguf = args.gguf or os.environ.get("BITNET_GGUF")
     cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers, gguf)
     if args.exact_act:
@@ -413,6 +492,9 @@ def main():
     # outside the timed region: the fast step against the UNFUSED step on the reference-order (bit-exact) kernels, same
     # weights, same short prompt, at the full model size -- a wrong fast kernel cannot hide behind a plausible rate
     check = exact_step_check(dec, synth, cfg)
+    stream_res = None
+    if not args.no_stream and args.workload in ("c2", "c3") and n_gpus == 1 and not gguf and not args.layers:
+        stream_res = i2s_stream(hip, synth, "i2s" if args.workload == "c2" else "qk256", args.stream_layers)
     prefill_chk = prefill_check(dec, prompt, PROMPT_LEN, args.digits, prefill_state) if prefill_state is not None else None
     # whole-step view of the same metric: all I2_S matrices of one token / step time
     wb = dec.weight_bytes()
@@ -456,6 +538,8 @@ def main():
             "distinct_tokens_in_timed_steps": int(len(set(int(t) for t in tokens[-args.steps:]))),
             "exact_step_check": check,
         }
+        if stream_res is not None:
+            out["i2s_stream"] = stream_res
         if prefill_ms is not None:
             flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * PROMPT_LEN + 4.0 * PROMPT_LEN * PROMPT_LEN / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
             out["prefill"] = {"tokens": PROMPT_LEN, "ms": round(prefill_ms, 2), "tokens_per_s": round(PROMPT_LEN / prefill_ms * 1e3, 1),

@@ -349,6 +349,16 @@ class HipLib:
                                                                     _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv, head_dim, max_pos,
                                                                     _ptr(workspace), workspace_bytes, _ptr(out), _vp(stream)))
 
+    def attention_prefill_gathered_dev(self, q, ld_q, q_block_pos, n_q, kv_gathered, n_ctx, world, kv_is_f16, rope_sin, rope_cos, kcache, vcache,
+                                       cache_f16, n_heads, n_kv, head_dim, max_pos, workspace, workspace_bytes, out, stream: int = 0) -> None:
+        """the k|v rows exactly as an all-gather over `world` ranks left them (rank-major zigzag chunks, f32 or f16)"""
+        self.c.bitnet_hip_attention_prefill_gathered_dev.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _sz, _sz,
+                                                                     _sz, _sz, _vp, _sz, _vp, _vp]
+        self._check(self.c.bitnet_hip_attention_prefill_gathered_dev(_ptr(q), ld_q, _ptr(q_block_pos), n_q, _ptr(kv_gathered), n_ctx, world,
+                                                                     int(kv_is_f16), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache),
+                                                                     int(cache_f16), n_heads, n_kv, head_dim, max_pos, _ptr(workspace), workspace_bytes,
+                                                                     _ptr(out), _vp(stream)))
+
     def weights_bind_ln(self, h: int, ln_gamma, stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_weights_bind_ln(h, _ptr(ln_gamma), _vp(stream)))
 

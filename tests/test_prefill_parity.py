@@ -304,14 +304,16 @@ def test_decode_switches_to_the_wide_attention_form(pkg, oracle, synth):
     om.close()
 
 
-@pytest.mark.parametrize("world,T,wire_f16", [(1, 128, False), (2, 256, False), (2, 512, True)])
+@pytest.mark.parametrize("world,T,wire_f16", [(1, 128, False), (2, 256, False), (2, 512, True), (8, 1024, True), (8, 8192, True)])
 def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T, wire_f16):
     """Decoder::prefill_sharded (the C++ host loop + bitnet_hip_attention_prefill_gathered_dev: zigzag chunks, k|v rows read
     in place from the gathered buffer) with `world` decoders = ranks on ONE GPU, each driven from its own host thread, the
     all-gather supplied as a callback that meets at a barrier -- against the unsharded Decoder.prefill."""
     import threading
 
-    cfg = synth.ModelConfig(**dict(SMALL, max_pos=640))
+    # world 8 = the driver's 8-GPU run rehearsed as eight rank threads on one GPU (16 zigzag chunks; 8192 tokens = 512-token
+    # chunks, the size bench.py's c5 line uses): its first execution on real ranks must not be the first execution of this indexing
+    cfg = synth.ModelConfig(**dict(SMALL, max_pos=max(640, T + 64)))
     layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
     glob = synth.make_globals(cfg)
     prompt = synth.prompt(T, cfg.vocab)
@@ -374,3 +376,65 @@ def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T
     with pytest.raises(pkg.BitNetHipError, match="multiple of"):
         dd = make()
         dd.prefill_sharded(100, 0, 2, lambda *a: 0)
+
+
+@pytest.mark.parametrize("wire_f16", [False, True])
+def test_gathered_attention_world8_8k_matches_unsharded_and_f64(hip, oracle, torch_, wire_f16):
+    """bitnet_hip_attention_prefill_gathered_dev exactly as the 8-GPU run of BASELINE configs[4] calls it: 8192 positions in 16
+    zigzag chunks of 512, the k|v rows in rank-major order as ncclAllGather leaves them (f32, or f16 on the wire), 2B-4T head
+    counts, one rank's 1024 queries per call.  f32 on the wire must reproduce the unsharded kernel's rows bit for bit and fill
+    the same cache; f16 on the wire is held to the f64 reference (the prompt attention rounds k, v to f16 anyway)."""
+    n_heads, n_kv, D, T, world, max_pos = 20, 5, 128, 8192, 8, 8192
+    chunk, nq, KD = T // (2 * world), T // world, n_kv * 128
+    rng = np.random.default_rng(8192)
+    qkv = rng.normal(0, 1.2, (T, (n_heads + 2 * n_kv) * D)).astype(np.float32)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a)).cuda()
+    sin_d, cos_d = dev(sin), dev(cos)
+    # unsharded: one call over the whole prompt
+    wsb = hip.attention_prefill_workspace_bytes(n_heads, n_kv, T)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    kc0, vc0 = torch_.zeros(n_kv * max_pos * D, device="cuda"), torch_.zeros(n_kv * max_pos * D, device="cuda")
+    base_d = torch_.empty(T, n_heads * D, device="cuda")
+    hip.attention_prefill_dev(dev(qkv), sin_d, cos_d, kc0, vc0, n_heads, n_kv, D, max_pos, T, ws, wsb, base_d)
+    torch_.cuda.synchronize()
+    base = base_d.cpu().numpy()
+    del ws, base_d
+    # the gathered buffer: rank r's block = chunk r, then chunk 2 world - 1 - r; each row = k heads then v heads
+    rows_of = lambda r: np.concatenate([np.arange(r * chunk, (r + 1) * chunk), np.arange((2 * world - 1 - r) * chunk, (2 * world - r) * chunk)])
+    order = np.concatenate([rows_of(r) for r in range(world)])
+    kv = qkv[:, n_heads * D:][order]
+    kv_d = dev(kv.astype(np.float16) if wire_f16 else kv)
+    wsb2 = hip.attention_prefill_sharded_workspace_bytes(n_heads, n_kv, nq, T)
+    ws2 = torch_.empty(wsb2, dtype=torch_.uint8, device="cuda")
+    for rank in (0, 3, 7):
+        rows = rows_of(rank)
+        q_local = dev(qkv[rows][:, : n_heads * D])
+        bp = dev(rows[::64].astype(np.int32))
+        kc, vc = torch_.zeros(n_kv * max_pos * D, device="cuda"), torch_.zeros(n_kv * max_pos * D, device="cuda")
+        out = torch_.full((nq, n_heads * D), float("nan"), device="cuda")
+        hip.attention_prefill_gathered_dev(q_local, n_heads * D, bp, nq, kv_d, T, world, wire_f16, sin_d, cos_d, kc, vc, False, n_heads, n_kv, D,
+                                           max_pos, ws2, wsb2, out)
+        torch_.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any()
+        if not wire_f16:
+            assert np.array_equal(got, base[rows]), rank
+            assert torch_.equal(kc, kc0) and torch_.equal(vc, vc0), rank  # every rank fills the whole cache
+        else:
+            assert np.max(np.abs(got - base[rows])) <= 6e-3 and cosine(got, base[rows]) >= 0.99999, rank
+            assert float((kc - kc0).abs().max()) <= 2e-3 * float(kc0.abs().max())
+    # f64 reference on a sample of rank 7's queries (first chunk 7 = positions 3584.., second chunk 8 = 4096..)
+    rows = rows_of(7)[[0, 63, 511, 512, 1000, 1023]]
+    q = qkv[:, : n_heads * D].reshape(T, n_heads, D).astype(np.float64)
+    k = qkv[:, n_heads * D:(n_heads + n_kv) * D].reshape(T, n_kv, D).astype(np.float64)
+    v = qkv[:, (n_heads + n_kv) * D:].reshape(T, n_kv, D).astype(np.float64)
+    sin2, cos2 = sin.reshape(max_pos, D // 2), cos.reshape(max_pos, D // 2)
+    k = rope_np(k, sin2[:T, None, :], cos2[:T, None, :])
+    for t in rows:
+        qt = rope_np(q[t], sin2[t][None, :], cos2[t][None, :])
+        for h in (0, 7, 19):
+            s = k[: t + 1, h // 4] @ qt[h] / np.sqrt(D)
+            pm = np.exp(s - s.max())
+            want = (pm / pm.sum()) @ v[: t + 1, h // 4]
+            assert np.max(np.abs(base[t, h * D:(h + 1) * D] - want)) <= 6e-3, (t, h)

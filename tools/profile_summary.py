@@ -32,12 +32,20 @@ def short(name: str) -> str:
 
 
 DOMINANT = ("k_gemv_q<8, 5", "k_gemv_mfma<8, 5")  # the fused gate|up GEMV (RING 5: paired matrix at K = 2560)
+DOMINANT_PREFILL = ("k_gemm_mfma",)               # prefill passes: the tiled matmul with the largest total time (gate|up)
+
+
+def newest(pattern_dir: str, suffix: str):
+    """ONE sitting: the newest file below a pass directory.  gpurun merges every call's output into the local gpurun_out/
+    without removing older files, so a directory can hold several sittings (one <pid>_*.csv each) -- VERDICT r02."""
+    files = glob.glob(os.path.join(pattern_dir, "**", "*" + suffix), recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
 
 
 def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
     wl = sys.argv[3] if len(sys.argv) > 3 else "c2"
-    trace = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    trace = newest(os.path.join(out_dir, "trace"), "kernel_trace.csv")
     k = collections.defaultdict(list)
     grids = collections.defaultdict(set)
     for f in trace:
@@ -47,7 +55,7 @@ def main():
     pmc = {}
     for cname, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0 * 1024.0), ("WRITE_SIZE", "pmc_write", 1024.0)):
         d = collections.defaultdict(list)
-        for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(os.path.join(out_dir, sub), "counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != cname:
                     continue
@@ -68,10 +76,15 @@ def main():
             "hbm_fetch_bytes_per_launch": round(sum(fetch) / len(fetch)) if fetch else None,
             "hbm_write_bytes_per_launch": round(sum(write) / len(write)) if write else None,
         })
+    sitting = "unknown"
+    try:
+        sitting = open(os.path.join(os.path.dirname(os.path.abspath(out_dir)), "SITTING")).read().strip()
+    except OSError:
+        pass
     with open(os.path.join(out_dir, "summary.json"), "w") as f:
-        json.dump({"tag": tag, "kernels": rows}, f, indent=1)
+        json.dump({"tag": tag, "sitting": sitting, "trace_file": os.path.basename(trace[0]) if trace else None, "kernels": rows}, f, indent=1)
     with open(os.path.join(out_dir, "summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary {tag}\n\n")
+        f.write(f"# rocprofv3 summary {tag} {wl} (sitting {sitting}: one trace file, one file per counter pass)\n\n")
         f.write("Times: `rocprofv3 --kernel-trace --stats`; bytes: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, ")
         f.write("fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024.\n\n")
         f.write("| kernel | WGs | calls | total ms | % | avg us | min | med | max | HBM fetch B/launch | HBM write B/launch |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
@@ -95,15 +108,16 @@ def main():
         wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         wr.writeheader()
         wr.writerows(rows)
-    dom = [r for r in rows if r["kernel"].startswith(DOMINANT) and r["hbm_fetch_bytes_per_launch"] is not None]
+    dom = [r for r in rows if r["kernel"].startswith(DOMINANT_PREFILL if wl.startswith("prefill") else DOMINANT) and r["hbm_fetch_bytes_per_launch"] is not None]
     if dom:
         d = max(dom, key=lambda r: r["total_ms"])
         with open(os.path.join(prof, f"traffic_{wl}.json"), "w") as f:
             json.dump({"round": tag, "workload": wl, "kernel": d["kernel"], "workgroups": d["workgroups"],
                        "hbm_fetch_bytes_per_launch": d["hbm_fetch_bytes_per_launch"], "hbm_write_bytes_per_launch": d["hbm_write_bytes_per_launch"] or 0,
                        "avg_us_rocprof": d["avg_us"],
-                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `python3 bench.py --workload " + wl +
-                                 " --prompt 8 --steps 8` (the bench's own hipGraph launch path, short run: tools/profile_round.sh says why); "
+                       "sitting": sitting,
+                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate short passes over the same launch path as the timed run "
+                                 "(tools/profile_round.sh lists the exact commands per workload); "
                                  "fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024"}, f, indent=1)
     print(open(os.path.join(out_dir, "summary.md")).read()[:3000])
 
