@@ -54,6 +54,18 @@ __device__ __forceinline__ float awave_sum(float v) {
     return (arl(v, 0) + arl(v, 16)) + (arl(v, 32) + arl(v, 48));
 }
 
+// In-kernel time stamps (s_memrealtime, 100 MHz): diagnostic build only (-DBH_STAMPS; tools/stamp_attn.py), 8 x u64 per workgroup.
+#ifdef BH_STAMPS
+#define BH_ASTAMP(i)                                                                                                        \
+    do {                                                                                                                    \
+        if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define BH_ASTAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
 // NH = 64-position halves per workgroup (256 threads each).  NH = 2: a workgroup covers 128 positions, its two halves
 // run the chunk algorithm side by side and meet in LDS, so there is ONE record per 128 positions: half as many
 // records for whoever merges them (the combine kernel, or the o-projection at short contexts) and, at 4k keys, 160
@@ -81,13 +93,15 @@ template <int NH, bool KV16>
 __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restrict__ qkv, const float *__restrict__ rope_sin,
                                                            const float *__restrict__ rope_cos, float *__restrict__ kcache,
                                                            float *__restrict__ vcache, int n_heads, int n_kv, int group, int max_pos,
-                                                           const int *__restrict__ pos_ptr, float *__restrict__ scratch) {
+                                                           const int *__restrict__ pos_ptr, float *__restrict__ scratch,
+                                                           unsigned long long *stamps /* diagnostic builds only */) {
     // every kernel argument is requested together with pos_ptr: left alone hipcc fetches the others only behind
     // the early exit, a second dependent scalar-load round trip for the workgroups that stay
     asm volatile("" ::"s"(qkv), "s"(rope_sin), "s"(rope_cos), "s"(kcache), "s"(vcache), "s"(n_heads), "s"(n_kv), "s"(group), "s"(max_pos), "s"(scratch));
     const int pos = *pos_ptr, t_k = pos + 1;
     const int kvh = blockIdx.x, pc = blockIdx.y;
     if (pc * NH * kAttnChunk >= t_k) return;  // record beyond the context (the grid is sized for max_pos)
+    BH_ASTAMP(0);  // the position has arrived (a dependent scalar load behind the kernel arguments)
     __shared__ __attribute__((aligned(16))) float qs[kMaxGroup * kD];
     __shared__ __attribute__((aligned(16))) float kn[kD];
     __shared__ float vn[kD];
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep hipcc from moving the RoPE arithmetic (and its wait) up between the loads
+    BH_ASTAMP(1);  // every load of this thread is requested
     // ---- RoPE on the group's queries (and, in the owning half, on the new key) ----------
     if (half == 0) {
         float a = 0.0f, b = 0.0f;
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         }
     }
     __syncthreads();
+    BH_ASTAMP(2);  // q, the new key / value are in LDS (the seven RoPE operands have arrived)
     // ---- scores: lane = position, wave = 32-dim slice; all 32 loads of a thread in flight ---
     // Two partial sums per head (even / odd dims) so that each v_pk_fma_f32 takes an adjacent (q[d], q[d+1]) pair
     // from one LDS read and an adjacent (k[d], k[d+1]) register pair: no operand shuffling.
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
 #pragma unroll
         for (int g = 0; g < kMaxGroup; ++g) partial[half][wave][lane][g] = acc[g][0] + acc[g][1];
     }
+    BH_ASTAMP(3);  // scores done: the K slice has arrived
     __syncthreads();
     // ---- chunk-local softmax pieces: wave g owns head g, lane = position ---------------------
     // (positions past the context carried stale keys: their scores, whatever they are, are replaced here;
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         }
     }
     __syncthreads();
+    BH_ASTAMP(4);  // softmax weights in LDS
     // ---- un-normalised P.V: thread = (dim d, position parity hp); V already in registers ---
     float *rec = scratch + ((size_t)kvh * gridDim.y + pc) * kRec;
     if (KV16) {
@@ -378,6 +396,7 @@ __global__ __launch_bounds__(256 * NH) void k_attn_partial(const float *__restri
         rec[2 * wave] = m_c;
         rec[2 * wave + 1] = l_c;
     }
+    BH_ASTAMP(5);
 }
 
 // One workgroup per head: 8 thread groups walk the chunk records in parallel (chunk c -> group
@@ -487,7 +506,7 @@ hipError_t launch_attn_decode(const float *qkv, const float *rope_sin, const flo
     const int n_rec = (max_pos + rec_pos - 1) / rec_pos;
     auto kfn = halves == 2 ? (kv_f16 ? k_attn_partial<2, true> : k_attn_partial<2, false>) : (kv_f16 ? k_attn_partial<1, true> : k_attn_partial<1, false>);
     hipLaunchKernelGGL(kfn, dim3(n_kv, n_rec), dim3(256 * halves), 0, stream, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, n_heads / n_kv,
-                       max_pos, pos_ptr, scratch);
+                       max_pos, pos_ptr, scratch, g_mfma_stamps);
     // combine == false: the chunk records stay in `scratch` for a consumer that merges them itself
     // (launch_gemv_mfma with GemvFusion::attn_rec)
     if (combine) {

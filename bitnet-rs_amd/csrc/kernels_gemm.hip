@@ -541,6 +541,251 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     }
 }
 
+// ================================================================================================================================
+// BitNet32-F16 (ternary codes x one f16 scale per 32 weights) on the f16 matrix cores: "2-bit weight unpack x f16 activation dot
+// product, per-block scale" as north_star words it.  The int8 digit form above has to fold every 32-block's integer sums into f32
+// with that block's scale -- 3 VALU per (row, token, block), 768 of the 980 VALU instructions of a K step -- which
+// made the headline storage format prefill at HALF the QK256 rate.  Here the block scale is folded into the WEIGHT instead:
+// the A operand of v_mfma_f32_16x16x32_f16 is (+-s or 0) as f16 -- exact, s is an f16 value -- so one MFMA = one 32-block whose
+// result accumulates straight into the f32 accumulator of the whole K loop: no fold, no per-block epilogue, and one MFMA per
+// (block, row tile, token tile) instead of two digit MFMAs.  Activations are f16 with one power-of-two scale per row (row maximum
+// in [1, 2): 11-bit mantissa per ELEMENT, 2^-12 relative rounding each), staged [token][K] in LDS.
+//   expand: code bytes c -> selector bytes [0x0C, c_a, 0x0C, c_b] (v_perm_b32) -> f16 pair (t_a, t_b), t = code map value, through a
+//   LUT of the values' HIGH bytes (every value in {-2 .. 2} has a zero low byte) -> v_pk_mul_f16 by (s, s): 16 VALU per 8 weights.
+// Tile: 256 weight rows x 16 TTW tokens per 4-wave workgroup, two per CU, as the QK256 form.
+
+// activation rows -> f16 planes [row][kp] (zero padded), inv_scale[row] = 2^E (0 for padding rows)
+template <int NV>
+__global__ __launch_bounds__(256) void k_quant_rows_f16(QuantArgs p) {
+    __shared__ double stat[8];
+    __shared__ float smax[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nvec = p.cols >> 2, kvec = p.kp >> 2;
+    const bool live = row < p.m;
+    const int rr = live ? row : p.m - 1;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, ci = idx < nvec ? idx : nvec - 1;
+        v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        if (idx >= nvec || !live) v[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.ln_gamma) {  // LayerNorm without bias, with mean subtraction (T:67-100): the same arithmetic as k_quant_rows
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double a = v[i].x, b = v[i].y, c = v[i].z, d = v[i].w;
+            s1 += (a + b) + (c + d);
+            s2 += (a * a + b * b) + (c * c + d * d);
+        }
+        s1 = qwave_sum_d(s1);
+        s2 = qwave_sum_d(s2);
+        if (lane == 0) {
+            stat[2 * wave] = s1;
+            stat[2 * wave + 1] = s2;
+        }
+        __syncthreads();
+        s1 = (stat[0] + stat[2]) + (stat[4] + stat[6]);
+        s2 = (stat[1] + stat[3]) + (stat[5] + stat[7]);
+        const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
+        const float mean = (float)mean_d, denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nvec && live) {
+                const float4 g = *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * idx);
+                v[i].x = (v[i].x - mean) / denom * g.x;
+                v[i].y = (v[i].y - mean) / denom * g.y;
+                v[i].z = (v[i].z - mean) / denom * g.z;
+                v[i].w = (v[i].w - mean) / denom * g.w;
+            }
+        }
+    }
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    am = qwave_max(am);
+    if (lane == 0) smax[wave] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
+    be = be < 32 ? 32 : be > 253 ? 253 : be;
+    const float sc = __uint_as_float((uint32_t)(254 - be) << 23);  // 2^-E: the row maximum lands in [1, 2)
+    const float inv_s = __uint_as_float((uint32_t)be << 23);       // 2^E
+    if (tid == 0) p.inv_scale[row] = live ? inv_s : 0.0f;
+    _Float16 *base = reinterpret_cast<_Float16 *>(p.planes) + (size_t)row * p.kp;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx >= kvec) continue;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 o = {(_Float16)(v[i].x * sc), (_Float16)(v[i].y * sc), (_Float16)(v[i].z * sc), (_Float16)(v[i].w * sc)};
+        *reinterpret_cast<h4 *>(base + 4 * idx) = o;
+    }
+}
+
+typedef _Float16 gh2 __attribute__((ext_vector_type(2)));
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+typedef float gv4f __attribute__((ext_vector_type(4)));
+constexpr int kRowStrideH = 528;  // LDS bytes per token row of the f16 activation tile: 256 halves + 16 bytes
+
+template <int TTW>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_hi) {
+    constexpr int WG_TOK = TTW * 16;
+    constexpr int NB = WG_TOK * 32 / 256;  // 16-byte segments per thread per K step (32 per token row)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4, rw = wave;
+    const int n_tiles = (p.rows + 15) >> 4;
+    const int kp = p.nblk * 256;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {  // one XCD works through consecutive logical ids (k_gemm_mfma explains)
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if ((total & 7) == 0) {
+            const int l = (id & 7) * (total >> 3) + (id >> 3);
+            bx = l % gx;
+            by = l / gx;
+        }
+    }
+    const uint8_t *wptr[4];
+    const uint32_t *sptr[4];  // this lane's row of the f16 scale tiles: dword (kg, row c) = blocks 2 kg, 2 kg + 1
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        int t = bx * 16 + rw * 4 + rt;
+        t = t < n_tiles ? t : n_tiles - 1;
+        wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
+        sptr[rt] = reinterpret_cast<const uint32_t *>(p.stiles_h) + (size_t)t * p.nblk * 64 + c;
+    }
+    const _Float16 *planes = reinterpret_cast<const _Float16 *>(p.planes);
+    const uint8_t *bsrc[NB];
+    int bdst[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + 256 * i, tok = idx >> 5, seg = idx & 31;
+        bsrc[i] = reinterpret_cast<const uint8_t *>(planes + (size_t)(by * WG_TOK + tok) * kp) + seg * 16;
+        bdst[i] = tok * kRowStrideH + seg * 16;
+    }
+    constexpr int kBuf = WG_TOK * kRowStrideH;
+    uint8_t *wst = lds + kBuf + wave * 4096;                // this wave's tile staging area (the K = 32 deal, as WS == 3)
+    const uint8_t *wrd = wst + c * 16 + 4 * (g >> 1);
+    const int sh3 = 4 * (g & 1);
+    const uint8_t *bread = lds + c * kRowStrideH + 16 * g;  // token c of a 16-token tile, this lane's 8 k of 32-block 0
+    gv4f acc[4][TTW];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
+    gv4u wn[4], bn[NB];
+    uint32_t sn[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) sn[rt][kg] = sptr[rt][kg * 16];
+
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        __syncthreads();  // the previous step's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<gv4u *>(wst + rt * 1024 + lane * 16) = wn[rt];
+        uint32_t sc[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) sc[rt][kg] = sn[rt][kg];
+        __syncthreads();
+        {  // the next step's loads are in flight during this step's MFMAs
+            const int nx = blk + 1 < p.nblk ? blk + 1 : blk;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)nx * 1024);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)nx * 512);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) sn[rt][kg] = sptr[rt][(size_t)nx * 64 + kg * 16];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // 64-column group i = 32-blocks 2 i, 2 i + 1 of this 256-block
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                gh8 a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    // eight 2-bit fields = this lane's 8 k of the block (the deal of WS == 3)
+                    const uint32_t wd = *reinterpret_cast<const uint32_t *>(wrd + rt * 1024 + i * 256 + 8 * hb) >> sh3;
+                    const uint32_t ca = wd & 0x03030303u, cb = (wd >> 2) & 0x03030303u;
+                    // (s, s) of block 2 i + hb
+                    const uint32_t ss = __builtin_amdgcn_perm(0u, sc[rt][i], hb ? 0x03020302u : 0x01000100u);
+                    const gh2 s2 = __builtin_bit_cast(gh2, ss);
+                    uint32_t t[4];
+                    t[0] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x01040004u));
+                    t[1] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x03040204u));
+                    t[2] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x01040004u));
+                    t[3] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x03040204u));
+                    gh2 w2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w2[q] = __builtin_bit_cast(gh2, t[q]) * s2;
+                    a[rt] = (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
+                }
+#pragma unroll
+                for (int ct = 0; ct < TTW; ++ct) {
+                    const gh8 b = *reinterpret_cast<const gh8 *>(bread + ct * 16 * kRowStrideH + 128 * i + 64 * hb);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: x 2^E_t, [residual | silu * mul], store (k_gemm_mfma's) ------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        const int token = (by * TTW + tt) * 16 + c;
+        if (token >= p.m) continue;
+        const float is = p.inv_scale[token];
+        float val[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
+        if (!p.silu_mul) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int row0 = 16 * (bx * 16 + rw * 4 + rt) + 4 * g;
+                const size_t off = (size_t)token * p.rows + row0;
+                if (row0 + 3 < p.rows && (p.rows & 3) == 0) {
+                    float4 o = {val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
+                    if (p.residual) {
+                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
+                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+                    }
+                    *reinterpret_cast<float4 *>(p.y + off) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + j < p.rows) p.y[off + j] = val[rt][j] + (p.residual ? p.residual[off + j] : 0.0f);
+                }
+            }
+        } else {
+            const int half_rows = p.rows >> 1;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
+                const size_t off = (size_t)token * half_rows + row0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
+                    if (row0 + j < half_rows) p.y[off + j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+            }
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 constexpr size_t kGemmCUs = 256;
 thread_local GemmTileChoice g_last_gemm_tile;  // what the last launch on this thread ran (bitnet_hip_matmul_last_tile)
@@ -617,6 +862,32 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     return hipGetLastError();
 }
 
+// code map values -> the high bytes of their f16 images (every value of the reference's maps, -2 .. 2, has a zero low byte)
+static uint32_t lut_f16_hi(uint32_t lut) {
+    uint32_t out = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int v = (int)(int8_t)((lut >> (8 * c)) & 0xffu);
+        const uint32_t hi = v == 0 ? 0x00u : v == 1 ? 0x3Cu : v == -1 ? 0xBCu : v == 2 ? 0x40u : v == -2 ? 0xC0u : 0xFFu;
+        out |= hi << (8 * c);
+    }
+    return out;
+}
+
+static hipError_t launch_gemm_f16w(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
+    const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
+    void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows_f16<3> : k_quant_rows_f16<8>;
+    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
+    // token tile: 64 (TTW 4) while the grid still covers the chip twice over, else narrower (short prompts, one rank's share)
+    const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
+    int ttw = 4;
+    while (ttw > 1 && gx0 * (q.m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+    void (*gk)(GemmArgs, uint32_t) = ttw == 4 ? k_gemm_f16w<4> : ttw == 2 ? k_gemm_f16w<2> : k_gemm_f16w<1>;
+    const size_t lds = (size_t)ttw * 16 * kRowStrideH + 4 * 4096;
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 4};
+    hipLaunchKernelGGL(gk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
                             void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
@@ -651,6 +922,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
+    if (ndig == 2 && k32) return launch_gemm_f16w(w, q, a, stream);  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
     return launch_gemm_t<4, 2>(w, q, a, stream);

@@ -213,7 +213,8 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
                                  int kernel, void *stream);
 /* Many activation rows at once (prefill; forward_qk256's per-row loop T:683-691 as ONE tiled
  * matmul on the matrix cores).  Same fusions as gemv_fused_dev, per row.  `digits` = base-256
- * fixed-point digits per activation (4: the GEMV's 30 bits; 3: 22 bits; 2: 14 bits).
+ * fixed-point digits per activation (4: the GEMV's 30 bits; 3: 22 bits; 2: 14 bits -- on BitNet32-F16 matrices (32-element blocks
+ * with f16 scales) digits = 2 means f16 activations with one power-of-two scale per row, on the f16 matrix cores).
  * The int8 digit planes live in a caller-owned device workspace. */
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
 int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
@@ -222,7 +223,8 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
                                 void *stream);
 /* Which tile form the calling thread's last bitnet_hip_matmul_[fused_]dev launch ran (any pointer may be null): digits,
  * tokens per wave tile (16 / 32 / 64), waves per workgroup (4 / 8), weight-scale mode (0 none, 1 per 256-block, 2 per
- * 32-block on the masked K = 64 MFMA, 3 per 32-block on the K = 32 MFMA with f16 scale tiles).  The parity tests assert
+ * 32-block on the masked K = 64 MFMA, 3 per 32-block on the K = 32 int8 MFMA with f16 scale tiles, 4 the f16 MFMA with the block
+ * scale folded into f16 weights and f16 activations: BitNet32-F16 at digits = 2).  The parity tests assert
  * that the instance bench.py times (2 digits, 64-token tile) is the one they compared with the oracle. */
 int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode);
 
