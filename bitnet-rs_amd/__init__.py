@@ -138,7 +138,6 @@ class HipLib:
         L.bitnet_hip_gemv_q_dev.argtypes = [C.c_uint64, _vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_attention_decode_q_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, C.c_int, _vp, _vp, _vp]
         L.bitnet_hip_gemv_attn_merge_q_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
-        L.bitnet_hip_gemv_attn_merge_wide_q_dev.argtypes = [C.c_uint64, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.bitnet_hip_matmul_workspace_bytes.argtypes = [_sz, _sz, C.c_int]
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
@@ -423,12 +422,6 @@ class HipLib:
                               stream: int = 0) -> None:
         self._check(self.c.bitnet_hip_gemv_attn_merge_q_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _optr(residual),
                                                             _ptr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
-
-    def gemv_attn_merge_wide_q_dev(self, h: int, scratch, n_heads, n_kv, max_pos, pos, y, qact_out, residual=None, gamma_out=None,
-                                   stats_out=None, stream: int = 0) -> None:
-        """the same on 128-position records (attention_decode_q_dev with ATTN_WIDE | ATTN_PARTIAL): up to 512 keys"""
-        self._check(self.c.bitnet_hip_gemv_attn_merge_wide_q_dev(h, _ptr(scratch), n_heads, n_kv, max_pos, _ptr(pos), _ptr(y), _optr(residual),
-                                                                 _ptr(qact_out), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
     def weights_concat(self, parts, interleave16: bool = False) -> int:
         arr = (C.c_uint64 * len(parts))(*parts)

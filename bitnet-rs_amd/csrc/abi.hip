@@ -819,7 +819,6 @@ int bitnet_hip_attention_decode_partial_dev(const float *qkv, const float *rope_
 }
 
 size_t bitnet_hip_attention_merge_max_keys(void) { return (size_t)4 * 64; }
-size_t bitnet_hip_attention_merge_max_keys_wide(void) { return (size_t)4 * 128; }
 
 static int gemv_attn_merge(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads, size_t max_pos,
                            const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out, const float *gamma_out_dev,
@@ -877,13 +876,6 @@ int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t h, const float *attn_s
                                      const float *gamma_out_dev, double *stats_out, void *stream) {
     if (!qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_q_dev");
     return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, qact_out, gamma_out_dev, stats_out, stream);
-}
-
-int bitnet_hip_gemv_attn_merge_wide_q_dev(bitnet_hip_weights_t h, const float *attn_scratch_dev, size_t n_heads, size_t n_kv_heads,
-                                          size_t max_pos, const int32_t *pos_dev, float *y_dev, const float *residual_dev, void *qact_out,
-                                          const float *gamma_out_dev, double *stats_out, void *stream) {
-    if (!qact_out) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to gemv_attn_merge_wide_q_dev");
-    return gemv_attn_merge(h, attn_scratch_dev, n_heads, n_kv_heads, max_pos, pos_dev, y_dev, residual_dev, qact_out, gamma_out_dev, stats_out, stream, 7);
 }
 
 /* ---- QAct: activations quantised by their producer (csrc/qact.hpp) ---- */

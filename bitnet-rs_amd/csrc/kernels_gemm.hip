@@ -825,8 +825,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     // 4096 tokens is 640 workgroups on 512 slots instead of 320 wide ones on 256 CUs.  Measured against the 8-wave tile (and
     // the spilling 128-register half-width form that used to take the 2560-row launches), 4096 tokens, 2 digits, quantiser
     // included: gate|up 370 -> 346 us, q|k|v 105 -> 97, o 104 -> 76, down 257 -> 188.
-    static const bool wide8 = getenv("BITNET_HIP_GEMM_WIDE8") && atoi(getenv("BITNET_HIP_GEMM_WIDE8")) == 1;  // the 8-wave forms, for A/B runs
-    if (!wide8 && (!scaled_variant || k32)) {
+    if (!scaled_variant || k32) {
         gk = k32 ? k_gemm_mfma<NDIG, TT32, 3, 2, 1> : k_gemm_mfma<NDIG, TTW, 0, 2, 1>;
         cw = 1;
         if (NDIG == 2 && !scaled_variant) {
@@ -836,12 +835,6 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             while (ttw > 1 && gx0 * (q.m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
             if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
             if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
-        }
-    } else if (NDIG == 2 && !scaled_variant) {
-        const size_t wide = div_ceil(div_ceil(w.rows, 16), 16) * (size_t)(q.m_pad / 128), rounds = div_ceil(wide, kGemmCUs);
-        if ((double)wide / (double)(rounds * kGemmCUs) < 0.8) {
-            gk = k_gemm_mfma<2, 2, 0, 4>;
-            ttw = 2;
         }
     }
     const size_t lds = (size_t)cw * NDIG * ttw * 16 * kColStride * (scaled_variant ? 1 : 2) + (k32 ? (size_t)4 * cw * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging

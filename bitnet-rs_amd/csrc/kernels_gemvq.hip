@@ -472,15 +472,10 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
     a.cols = (int)w.cols;
     a.nblk = (int)(w.cols / 256);
     a.lut = w.lut;
-    // tuning knob, read once: 16-wave workgroups (4 waves per SIMD, half the K range each; same grid as the 8-wave form) --
-    // bit 0: paired matrices (gate|up), bit 1: K of >= 16 blocks (down)
-    static const int nw16_mask = getenv("BITNET_HIP_Q_NW16") ? atoi(getenv("BITNET_HIP_Q_NW16")) : 0;
-    const int ks8 = mfma_pick_ksplit(w.rows, w.cols, io.silu_mul, 8);
-    const bool nw16 = ((nw16_mask & 1) && io.silu_mul && ks8 <= 4 && (size_t)(2 * ks8) <= w.cols / 256) ||
-                      ((nw16_mask & 2) && !io.silu_mul && ks8 == 8 && w.cols / 256 >= 16);
-    const int nw = nw16 ? 16 : 8;
-    const int ksplit = nw16 ? 2 * ks8 : ks8;
-    a.ks_log2 = ksplit == 16 ? 4 : ksplit == 8 ? 3 : ksplit == 4 ? 2 : ksplit == 2 ? 1 : 0;
+    // (16-wave workgroups -- 4 waves per SIMD, half the K range each -- measured slower in round 2, gate|up 5.46 vs 5.23 us, and were removed)
+    const int nw = 8;
+    const int ksplit = mfma_pick_ksplit(w.rows, w.cols, io.silu_mul, 8);
+    a.ks_log2 = ksplit == 8 ? 3 : ksplit == 4 ? 2 : ksplit == 2 ? 1 : 0;
     a.qin = static_cast<const uint8_t *>(io.qin);
     const bool ln = io.ln_gamma != nullptr;
     if (ln && !(w.ln_g && w.ln_gamma_bound == io.ln_gamma && io.stats_in)) return hipErrorInvalidValue;  // LayerNorm only in the after-product form
@@ -514,17 +509,9 @@ hipError_t launch_gemv_q(const Weights &w, const GemvQIo &io, hipStream_t stream
         kfn = ln ? (sc == 2 ? k_gemv_q<8, RINGv, 2, 1, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 1, NCPv> : k_gemv_q<8, RINGv, 0, 1, NCPv>)  \
                  : (sc == 2 ? k_gemv_q<8, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<8, RINGv, 1, 0, NCPv> : k_gemv_q<8, RINGv, 0, 0, NCPv>);
 #define BH_QPICK(RINGv) BH_QPICK2(RINGv, 1) BH_QPICK2(RINGv, 2) BH_QPICK2(RINGv, 3)
-    if (nw == 8) {
-        BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
-    }
+    BH_QPICK(2) BH_QPICK(3) BH_QPICK(4) BH_QPICK(5)
 #undef BH_QPICK
 #undef BH_QPICK2
-#define BH_QPICK16(RINGv, NCPv)                                                                                                          \
-    if (!kfn && nw == 16 && ring <= RINGv && ncp == NCPv)                                                                                \
-        kfn = ln ? (sc == 2 ? k_gemv_q<16, RINGv, 2, 1, NCPv> : sc == 1 ? k_gemv_q<16, RINGv, 1, 1, NCPv> : k_gemv_q<16, RINGv, 0, 1, NCPv>)  \
-                 : (sc == 2 ? k_gemv_q<16, RINGv, 2, 0, NCPv> : sc == 1 ? k_gemv_q<16, RINGv, 1, 0, NCPv> : k_gemv_q<16, RINGv, 0, 0, NCPv>);
-    BH_QPICK16(2, 1) BH_QPICK16(2, 2) BH_QPICK16(3, 1) BH_QPICK16(3, 2) BH_QPICK16(4, 1) BH_QPICK16(4, 2)
-#undef BH_QPICK16
     if (io.attn_rec) {  // merging form: the o-projection shape (K = heads * 128 <= 4096: 8 elements per thread at most, ring <= 2)
         const int ne = (int)div_ceil(w.cols / 4, (size_t)512);  // 4-element slots per thread
         if (ln || nw != 8 || ring > 2 || ncp != 1 || w.cols % 128 != 0 || ne > 2 || !io.attn_pos || io.attn_chunks_max < 1) return hipErrorInvalidValue;

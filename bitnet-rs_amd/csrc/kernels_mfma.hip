@@ -668,10 +668,7 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
     a.cols = (int)w.cols;
     a.nblk = (int)div_ceil(w.cols, 256);
     a.lut = w.lut;
-    // many row tiles: 16-wave workgroups, one per CU, so no second workgroup's activation loads
-    // queue behind the first one's weight stream in the CU's memory pipeline
-    static const bool nw16_env = getenv("BITNET_HIP_NW16") != nullptr;  // tuning knob, read once (never on the launch path)
-    const int nw = (nw16_env && div_ceil(w.rows, 16) >= 512) ? 16 : 8;
+    const int nw = 8;  // (16-wave workgroups were a round-1 tuning knob that never paid: removed)
     a.ksplit = mfma_pick_ksplit(w.rows, w.cols, fu.silu_mul, nw);
     a.ks_log2 = a.ksplit == 8 ? 3 : a.ksplit == 4 ? 2 : a.ksplit == 2 ? 1 : 0;
     a.inv_cols = 1.0 / (double)w.cols;
@@ -715,7 +712,6 @@ hipError_t launch_gemv_mfma(const Weights &w, const float *x, float *y, size_t m
         kfn = bs32 == 2 ? k_gemv_mfma<8, 2, 1, 0, 2, 1> : bs32 == 1 ? k_gemv_mfma<8, 2, 1, 0, 1, 1> : k_gemv_mfma<8, 2, 1, 0, 0, 1>;
     }
     BH_PICK(8, 2, 2) BH_PICK(8, 2, 4) BH_PICK(8, 3, 2) BH_PICK(8, 3, 4) BH_PICK(8, 4, 2) BH_PICK(8, 4, 4) BH_PICK(8, 5, 2) BH_PICK(8, 5, 4)
-    BH_PICK(16, 2, 1) BH_PICK(16, 2, 2) BH_PICK(16, 3, 1) BH_PICK(16, 3, 2) BH_PICK(16, 4, 1) BH_PICK(16, 4, 2)
 #undef BH_PICK
     if (!kfn) return hipErrorInvalidValue;
     const int ring_t = ring <= 2 ? 2 : ring;  // the instantiated RING (LDS plane stride)

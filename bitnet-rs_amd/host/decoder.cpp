@@ -374,7 +374,7 @@ int Decoder::position() {
 // (the o-projection merges them), 2 two kernels with 128-position records; out / qout: f32 output and / or its QAct.
 int Decoder::attn_launch(Layer &L, int form, float *out, void *qout) {
     // forms (form_at): 0 = 64-position records + combine, 1 = 64-position records merged by the o-projection (<= 256 keys),
-    //                  2 = 128-position records + combine, 3 = 128-position records merged by the o-projection (<= 512 keys)
+    //                  2 = 128-position records + combine
     const int flags = (form >= 2 ? BITNET_HIP_ATTN_WIDE : 0) | ((form & 1) ? BITNET_HIP_ATTN_PARTIAL : 0) | (kv_f16_ ? BITNET_HIP_ATTN_KV_F16 : 0);
     BCHK(bitnet_hip_attention_decode_q_dev(qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,
                                            (size_t)c_.max_pos, pos_, attn_scratch_, flags, out, qout, stream_));
@@ -459,9 +459,6 @@ int Decoder::step_launches(bool with_logits, int form, Tracer *tr) {
             if (form == 1) {
                 if (int rc = attn_launch(L, 1, nullptr, nullptr)) return rc;
                 BCHK(bitnet_hip_gemv_attn_merge_q_dev(L.o, attn_scratch_, NH, NK, MP, pos_, x2_, x_, qa_x2_, L.ffn_norm, st_x2_, s));
-            } else if (form == 3) {
-                if (int rc = attn_launch(L, 3, nullptr, nullptr)) return rc;
-                BCHK(bitnet_hip_gemv_attn_merge_wide_q_dev(L.o, attn_scratch_, NH, NK, MP, pos_, x2_, x_, qa_x2_, L.ffn_norm, st_x2_, s));
             } else {
                 if (int rc = attn_launch(L, form, tr ? att_ : nullptr, qa_att_)) return rc;
                 TRACE(bp + "attn_out", "attn_out", (int)l, att_, tQD);
@@ -621,11 +618,8 @@ int Decoder::form_at(int pos) const {
     static const bool wide_env = !(getenv("BITNET_HOST_ATTN_WIDE") && atoi(getenv("BITNET_HOST_ATTN_WIDE")) == 0);
     const int keys = pos + 1;
     if (merge_env && merge_ok_ && keys <= (int)bitnet_hip_attention_merge_max_keys()) return 1;
-    // 257..512 keys as four records of 128 positions, still merged by the o-projection (no combine launch): measured SLOWER than
-    // 64-position records + combine on the 2B-4T shapes (c2 1201-1214 vs 1224 tok/s: the 128-position attention launch costs
-    // more than the combine launch it saves, and 160 projection workgroups re-read four 2-KiB records each) -- opt-in
-    static const bool merge_wide_env = getenv("BITNET_HOST_ATTN_MERGE_WIDE") && atoi(getenv("BITNET_HOST_ATTN_MERGE_WIDE")) == 1;
-    if (merge_env && merge_wide_env && merge_ok_ && qact_path() && keys <= (int)bitnet_hip_attention_merge_max_keys_wide()) return 3;
+    // (257..512 keys as four 128-position records merged by the o-projection measured SLOWER than 64-position records + combine --
+    // c2 1201-1214 vs 1224 tok/s, round 2 -- and was removed in round 3)
     if (wide_env && c_.n_kv_heads * ((keys + 63) / 64) > 256) return 2;  // more 64-position chunks than CUs
     return 0;
 }

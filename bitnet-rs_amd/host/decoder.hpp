@@ -194,8 +194,8 @@ class Decoder {
     void *pf_gemm_ws_ = nullptr, *pf_attn_ws_ = nullptr;
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;
-    static constexpr int kGraphs = 8;
-    void *graph_exec_[kGraphs] = {};  // [2 * form + with_logits], forms 0..3 (form_at)
+    static constexpr int kGraphs = 6;
+    void *graph_exec_[kGraphs] = {};  // [2 * form + with_logits], forms 0..2 (form_at)
     void *graph_[kGraphs] = {};
     int logits_wgs_ = 512;  // two workgroups per CU: whole rounds on the 256 CUs (768 / 1280 workgroups are 15-20 % slower)
 };

@@ -385,14 +385,6 @@ int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t w, const float *attn_s
                                      size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
                                      const float *residual_dev, void *qact_out, const float *gamma_out_dev,
                                      double *stats_out, void *stream);
-/* The same on the records of the 128-position form (bitnet_hip_attention_decode_q_dev with BITNET_HIP_ATTN_WIDE |
- * BITNET_HIP_ATTN_PARTIAL): up to bitnet_hip_attention_merge_max_keys_wide() = 512 keys are four records, so contexts of
- * 257..512 keys also run without the combine launch. */
-size_t bitnet_hip_attention_merge_max_keys_wide(void);
-int bitnet_hip_gemv_attn_merge_wide_q_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
-                                     size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,
-                                     const float *residual_dev, void *qact_out, const float *gamma_out_dev,
-                                     double *stats_out, void *stream);
 /* The same attention for a whole prompt of seq_len tokens on a FRESH cache (positions
  * 0..seq_len-1): RoPE, cache append, causal GQA softmax attention (T:398-543 with the causal
  * mask T:452-470).  qkv_dev: [seq_len, n_heads*D + 2*n_kv*D]; out_dev: [seq_len, n_heads*D].

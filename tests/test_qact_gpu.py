@@ -310,25 +310,4 @@ def test_merging_oproj_on_qact_path_equals_combine_then_project(hip, pkg, oracle
         assert np.max(np.abs(da - db)) <= 2e-4 * max(1.0, np.max(np.abs(da)))
         assert np.array_equal(q2.cpu().numpy(), quantize_qact(b, gam.cpu().numpy()))  # its own output, quantised exactly as specified
         assert torch_.equal(k1, k2) and torch_.equal(v1, v2)
-    # 128-position records (ATTN_WIDE | ATTN_PARTIAL) merged by the projection: up to 512 keys without the combine launch
-    assert hip.c.bitnet_hip_attention_merge_max_keys_wide() == 512
-    for pos in (0, 127, 128, 300, 383, 384, 511):
-        kc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
-        vc = rng.normal(0, 1, n_kv * max_pos * D).astype(np.float32)
-        qkv = dev(torch_, rng.normal(0, 1.5, (n_heads + 2 * n_kv) * D).astype(np.float32))
-        res = dev(torch_, rng.normal(0, 1, rows).astype(np.float32))
-        pos_d = torch_.tensor([pos], dtype=torch_.int32, device="cuda")
-        k1, v1, s1 = dev(torch_, kc), dev(torch_, vc), torch_.zeros(sb // 4 + 16, device="cuda")
-        qa, y1, q1, st1 = z(hip.qact_bytes(cols)), z(rows, torch_.float32), z(hip.qact_bytes(rows)), z(rows // 16 * 2, torch_.float64)
-        hip.attention_decode_q_dev(qkv, sin_d, cos_d, k1, v1, n_heads, n_kv, D, max_pos, pos_d, s1, None, qa)
-        hip.gemv_q_dev(w, qa, y=y1, residual=res, qact_out=q1, gamma_out=gam, stats_out=st1)
-        k2, v2, s2 = dev(torch_, kc), dev(torch_, vc), torch_.zeros(sb // 4 + 16, device="cuda") + 3.0
-        y2, q2, st2 = z(rows, torch_.float32), z(hip.qact_bytes(rows)), z(rows // 16 * 2, torch_.float64)
-        hip.attention_decode_q_dev(qkv, sin_d, cos_d, k2, v2, n_heads, n_kv, D, max_pos, pos_d, s2, None, None, wide=True, partial=True)
-        hip.gemv_attn_merge_wide_q_dev(w, s2, n_heads, n_kv, max_pos, pos_d, y2, q2, residual=res, gamma_out=gam, stats_out=st2)
-        torch_.cuda.synchronize()
-        a, b = y1.cpu().numpy(), y2.cpu().numpy()
-        assert np.max(np.abs(a - b)) <= 3e-5 * max(1.0, np.max(np.abs(a))), ("wide", n_heads, n_kv, pos, np.max(np.abs(a - b)))
-        assert np.array_equal(q2.cpu().numpy(), quantize_qact(b, gam.cpu().numpy()))
-        assert torch_.equal(k1, k2) and torch_.equal(v1, v2)
     hip.weights_free(w)
