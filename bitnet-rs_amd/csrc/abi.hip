@@ -1037,7 +1037,16 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const
                                               size_t n_ctx, size_t world, int kv_is_f16, const float *rope_sin, const float *rope_cos,
                                               void *kcache, void *vcache, int cache_f16, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                               void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    return bitnet_hip_attention_prefill_gathered_phase_dev(q, ld_q, q_block_pos, n_q, kv_gathered, n_ctx, world, kv_is_f16, rope_sin, rope_cos, kcache, vcache,
+                                                           cache_f16, n_heads, n_kv_heads, head_dim, max_pos, workspace, workspace_bytes, out, 0, stream);
+}
+
+int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q, size_t ld_q, const int32_t *q_block_pos, size_t n_q, const void *kv_gathered,
+                                                    size_t n_ctx, size_t world, int kv_is_f16, const float *rope_sin, const float *rope_cos,
+                                                    void *kcache, void *vcache, int cache_f16, size_t n_heads, size_t n_kv_heads, size_t head_dim,
+                                                    size_t max_pos, void *workspace, size_t workspace_bytes, float *out, int phase, void *stream) {
     BH_GUARD_BEGIN
+    if (phase < 0 || phase > 2) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: phase must be 0, 1 or 2, got %d", phase);
     int rc = check_prefill_args(q, kv_gathered, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, n_ctx);
     if (rc) return rc;
     if (n_q == 0 || !q_block_pos) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: n_q and q_block_pos must be given");
@@ -1049,7 +1058,7 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
     BH_HIP_TRY(launch_attn_prefill(q, (int)ld_q, q_block_pos, (int)n_q, static_cast<const float *>(kv_gathered), (int)(2 * n_kv_heads * head_dim), (int)n_ctx,
                                    rope_sin, rope_cos, static_cast<float *>(kcache), static_cast<float *>(vcache), (int)n_heads, (int)n_kv_heads, (int)head_dim,
-                                   (int)max_pos, workspace, workspace_bytes, out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0, cache_f16 ? 1 : 0));
+                                   (int)max_pos, workspace, workspace_bytes, out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0, cache_f16 ? 1 : 0, phase));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }

@@ -208,7 +208,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
                                int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream,
-                               int zz_world = 0, int kv_f16 = 0, int cache_f16 = 0);
+                               int zz_world = 0, int kv_f16 = 0, int cache_f16 = 0, int phase = 0);
 hipError_t launch_pack_cols(const float *src, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst, int f16, hipStream_t stream);
 hipError_t launch_stream_read(const void *buf, size_t bytes, unsigned *sink, hipStream_t stream);
 hipError_t launch_logits_f16(const void *table, const float *x, const float *gamma, float eps, int hidden, int vocab,

@@ -32,6 +32,7 @@ constexpr int kQB = 64;        // keys per tile; query rows come in 64-row block
 constexpr int kQPad = 128;     // query rows are padded to this (the largest workgroup query tile)
 constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
 constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
+constexpr int kTilesPerSplit = 16;  // key split (PrefillArgs::ksplit): key tiles one workgroup walks at least before a block is cut
 
 struct PrefillArgs {
     // element (head h, row t, dim d) of q / k / v sits at base + h * hs + t * ld + d
@@ -53,6 +54,14 @@ struct PrefillArgs {
     int zz_world, zz_chunk;  // ranks, tokens per chunk (T = 2 * world * chunk; chunk % 64 == 0)
     int kv_f16;              // the k|v rows travelled as f16 (half the bytes on the wire); k / v then point at _Float16
     int cache_f16;           // the decode caches hold f16 (kernels_attn.hip KV16 layout)
+    // key split: the key tiles of a query block are dealt to `ksplit` workgroups (blockIdx.z), each leaving an un-normalised partial
+    // (o, m, l) that k_prefill_merge combines -- for launches whose query blocks alone would not fill the chip (one rank's 1024
+    // queries x 8192 keys of the 8-GPU prefill are 160 workgroups with up to 128 key tiles each; a 1024-token prompt likewise)
+    int phase;               // 0: prepare q, k, v and attend; 1: the query slabs only (needs no k|v: runs beside the all-gather);
+                             // 2: the k / v slabs and the attention (the query slabs were prepared by a phase-1 call on the same workspace)
+    int ksplit;
+    float *part_o;           // [ksplit][nq_pad][heads][128]
+    float *part_ml;          // [ksplit][nq_pad][heads][2]  (running maximum in base-2 units, sum)
 };
 
 // row of absolute position t (a multiple of 64) in the gathered k|v buffer: chunk c = t / chunk belongs to rank c (first
@@ -73,6 +82,7 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[kQB][kPD + 4];  // + 4: float4 rows stay 16-byte aligned, columns spread over the banks
     const int slot = blockIdx.y, t0 = blockIdx.x * kQB, tid = threadIdx.x;
     const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
+    if ((p.phase == 1 && !is_q) || (p.phase == 2 && is_q)) return;
     const int n_rows = is_q ? p.nq : p.T;
     if (t0 >= (is_q ? p.nq_pad : p.Tpad)) return;
     const float *src = is_q ? p.q + (size_t)slot * p.hs_q
@@ -206,7 +216,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         if (lane == 0) atomicMax(&s_last, need);
     }
     __syncthreads();
-    const int kt_last = s_last;
+    int kt_first = 0, kt_last = s_last;
+    if (p.ksplit > 1) {
+        // this workgroup's share of the key tiles: a query block with n tiles is cut into ceil(n / kTilesPerSplit) parts (at most
+        // ksplit), so early blocks (few tiles) stay whole and late ones spread over the chip; surplus workgroups only mark their
+        // partial empty (m = -inf), which the merge skips
+        const int n_t = kt_last + 1;
+        int parts = (n_t + kTilesPerSplit - 1) / kTilesPerSplit;
+        parts = parts < p.ksplit ? parts : p.ksplit;
+        if ((int)blockIdx.z >= parts) {
+            if (g == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const size_t ro = ((size_t)blockIdx.z * p.nq_pad + qbase + 16 * q + c) * p.n_heads + h;
+                    *reinterpret_cast<float2 *>(p.part_ml + ro * 2) = float2{-INFINITY, 0.0f};
+                }
+            }
+            return;
+        }
+        const int per = (n_t + parts - 1) / parts;
+        kt_first = (int)blockIdx.z * per;
+        kt_last = kt_first + per - 1 < kt_last ? kt_first + per - 1 : kt_last;
+    }
     int qlim[NQ];  // highest visible key position of this lane's query in group q
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qlim[q] = p.causal ? bpos + 16 * q + c : p.T - 1;
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
     const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
 
-    for (int kt = 0; kt <= kt_last; ++kt) {
+    for (int kt = kt_first; kt <= kt_last; ++kt) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -283,7 +314,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
                 }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float m_new = fmaxf(m_run[q], mt);  // finite: key 0 is visible to every query
+            // finite: key 0 is visible to every query -- of the FIRST key split; a later split's first tile can lie wholly above a
+            // query's limit (its 64-row block spans several query groups): exp2(-inf - (-inf)) would be NaN, so the shift is clamped
+            const float m_new = fmaxf(fmaxf(m_run[q], mt), -3.0e38f);
             const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
             float lsum = 0.0f;
 #pragma unroll
@@ -341,6 +374,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const int qrow = qbase + 16 * q + c;
+        if (p.ksplit > 1) {  // un-normalised partial; padding rows are written too (the merge never reads them)
+            const size_t ro = ((size_t)blockIdx.z * p.nq_pad + qrow) * p.n_heads + h;
+            float *op = p.part_o + ro * kPD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<float4 *>(op + 16 * dt) = float4{o[q][dt][0], o[q][dt][1], o[q][dt][2], o[q][dt][3]};
+            if (g == 0) *reinterpret_cast<float2 *>(p.part_ml + ro * 2) = float2{m_run[q], l};
+            continue;
+        }
         if (qrow < p.nq) {
             const float inv = 1.0f / l;
             float *op = p.out + (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
@@ -353,19 +394,62 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     }
 }
 
+// out[row][head][:] = sum_s 2^(m_s - M) o_s / sum_s 2^(m_s - M) l_s over the key splits; 32 threads (4 dims each) per (row, head)
+__global__ __launch_bounds__(256) void k_prefill_merge(PrefillArgs p) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int d4 = (int)(i & 31);
+    const size_t rh = i >> 5;  // row * heads + head
+    if (rh >= (size_t)p.nq * p.n_heads) return;
+    const size_t row = rh / p.n_heads, h = rh - row * p.n_heads;
+    const size_t stride = (size_t)p.nq_pad * p.n_heads;
+    float M = -INFINITY;
+    for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, p.part_ml[(s * stride + rh) * 2]);  // split 0 always holds key 0: finite
+    float L = 0.0f;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float2 ml = *reinterpret_cast<const float2 *>(p.part_ml + (s * stride + rh) * 2);
+        if (ml.x == -INFINITY) continue;  // a part this block did not need: nothing but the mark was written
+        const float w = __builtin_amdgcn_exp2f(ml.x - M);
+        const float4 o = *reinterpret_cast<const float4 *>(p.part_o + (s * stride + rh) * kPD + 4 * d4);
+        L += w * ml.y;
+        a.x += w * o.x, a.y += w * o.y, a.z += w * o.z, a.w += w * o.w;
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<float4 *>(p.out + row * p.out_ld + h * p.out_hs + 4 * d4) = float4{a.x * inv, a.y * inv, a.z * inv, a.w * inv};
+}
+
+// key splits of a launch (grid.z): only when the query blocks alone leave CUs idle (fewer than two workgroups per CU), as many
+// as the longest block has 16-tile parts, at most 8
+static int attn_ksplit(int n_heads, int n_kv, int nq_pad, int T) {
+    const int group = n_heads / n_kv, hw = group % 4 == 0 ? 4 : group % 2 == 0 ? 2 : 1, qg = 16 * (4 / hw) * 2;
+    const long n_wg = (long)(nq_pad / qg) * (n_heads / hw);
+    const int tiles = (T + kQB - 1) / kQB;
+    if (n_wg >= 512) return 1;
+    const int s = (tiles + kTilesPerSplit - 1) / kTilesPerSplit;
+    return s < 1 ? 1 : s > 8 ? 8 : s;
+}
+
 static void launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
     const int group = p.n_heads / p.n_kv;
+    const unsigned z = (unsigned)p.ksplit;
     if (group % 4 == 0)  // 4 waves = the 4 heads of a KV head x 32 queries each; two such workgroups per CU
-        hipLaunchKernelGGL((k_prefill_attn<4, 4, 2>), dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((k_prefill_attn<4, 4, 2>), dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4), z), dim3(256), 0, stream, p);
     else if (group % 2 == 0)  // 2 heads x 2 wave columns x 32 queries
-        hipLaunchKernelGGL((k_prefill_attn<2, 4, 2>), dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((k_prefill_attn<2, 4, 2>), dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2), z), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((k_prefill_attn<1, 4, 2>), dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((k_prefill_attn<1, 4, 2>), dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads, z), dim3(256), 0, stream, p);
+    if (p.ksplit > 1)
+        hipLaunchKernelGGL(k_prefill_merge, dim3((unsigned)div_ceil((size_t)p.nq * p.n_heads * 32, 256)), dim3(256), 0, stream, p);
+}
+
+static size_t attn_f16_bytes(int n_heads, int n_kv, size_t qpad, size_t tpad) {
+    return div_ceil(((size_t)n_heads * qpad + 2 * (size_t)n_kv * tpad) * kPD * sizeof(_Float16), 256) * 256;
 }
 
 size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
     const size_t qpad = div_ceil((size_t)nq, kQPad) * kQPad, tpad = div_ceil((size_t)T, kQB) * kQB;
-    return ((size_t)n_heads * qpad + 2 * (size_t)n_kv * tpad) * kPD * sizeof(_Float16) + 256;
+    const int ks = attn_ksplit(n_heads, n_kv, (int)qpad, T);
+    return attn_f16_bytes(n_heads, n_kv, qpad, tpad) + (ks > 1 ? (size_t)ks * qpad * n_heads * (kPD + 2) * sizeof(float) : 0) + 256;
 }
 
 // q: nq query rows (stride ld_q floats) whose 64-row blocks sit at absolute positions q_block_pos
@@ -373,7 +457,8 @@ size_t attn_prefill_workspace_bytes(int n_heads, int n_kv, int nq, int T) {
 hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos, int nq, const float *kv, int ld_kv, int T,
                                const float *rope_sin, const float *rope_cos, float *kcache, float *vcache, int n_heads, int n_kv,
                                int D, int max_pos, void *workspace, size_t workspace_bytes, float *out, hipStream_t stream,
-                               int zz_world, int kv_f16, int cache_f16) {
+                               int zz_world, int kv_f16, int cache_f16, int phase) {
+    if (phase < 0 || phase > 2) return hipErrorInvalidValue;
     if (D != kPD || T <= 0 || nq <= 0 || T > max_pos || n_heads % n_kv != 0) return hipErrorInvalidValue;
     if (zz_world < 0 || (zz_world > 0 && (T % (2 * zz_world * kQB) != 0))) return hipErrorInvalidValue;
     if (!workspace || workspace_bytes < attn_prefill_workspace_bytes(n_heads, n_kv, nq, T)) return hipErrorInvalidValue;
@@ -410,7 +495,15 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.kh = p.qh + (size_t)n_heads * p.nq_pad * kPD;
     p.vt = p.kh + (size_t)n_kv * p.Tpad * kPD;
     p.out = out;
+    p.ksplit = attn_ksplit(n_heads, n_kv, p.nq_pad, T);
+    p.part_o = reinterpret_cast<float *>(ws + attn_f16_bytes(n_heads, n_kv, (size_t)p.nq_pad, (size_t)p.Tpad));
+    p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
+    p.phase = phase;
     const unsigned nbq = (unsigned)(p.nq_pad / kQB), nbk = (unsigned)(p.Tpad / kQB);
+    if (phase == 1) {  // the query slabs alone
+        hipLaunchKernelGGL(k_prefill_prep, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
     launch_attn_kernel(p, stream);
     return hipGetLastError();
@@ -453,7 +546,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.causal = causal;
     p.scale = scale;
     p.q_block_pos = nullptr;
-    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = 0;
+    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = p.phase = 0;
     p.nq = seq;
     p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;
@@ -467,6 +560,9 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.kh = p.qh + (size_t)n_heads * p.nq_pad * kPD;
     p.vt = p.kh + (size_t)n_heads * p.Tpad * kPD;
     p.out = out;
+    p.ksplit = attn_ksplit(n_heads, n_heads, p.nq_pad, seq);
+    p.part_o = reinterpret_cast<float *>(ws + attn_f16_bytes(n_heads, n_heads, (size_t)p.nq_pad, (size_t)p.Tpad));
+    p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     const unsigned nb = (unsigned)(p.nq_pad / kQB);
     hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(3 * n_heads)), dim3(256), 0, stream, p);
     launch_attn_kernel(p, stream);

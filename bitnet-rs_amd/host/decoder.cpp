@@ -175,6 +175,9 @@ Decoder::~Decoder() {
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_, sp_kv_send_, sp_kv_all_,
                     (void *)sp_block_pos_, (void *)sp_tokens_})
         if (p) hipFree(p);
+    if (sp_ev_pack_) hipEventDestroy((hipEvent_t)sp_ev_pack_);
+    if (sp_ev_gather_) hipEventDestroy((hipEvent_t)sp_ev_gather_);
+    if (comm_stream_) hipStreamDestroy((hipStream_t)comm_stream_);
     if (stream_) hipStreamDestroy((hipStream_t)stream_);
 }
 
@@ -850,6 +853,16 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
         sp_ctx_ = n;
     }
     hipStream_t s = (hipStream_t)stream_;
+    if (world > 1 && !comm_stream_) {  // the collective's own stream + the two events that tie it to the compute stream
+        hipStream_t cs;
+        hipEvent_t e1, e2;
+        HCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        comm_stream_ = cs;
+        HCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        sp_ev_pack_ = e1;
+        HCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        sp_ev_gather_ = e2;
+    }
     {
         // this rank's rows: chunk `rank`, then chunk 2 world - 1 - rank
         std::vector<int32_t> hist((size_t)n), tok(N), bp(N / 64);
@@ -873,12 +886,23 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         // the raw (pre-RoPE) k|v rows this rank contributes, compact, f32 or f16
         BCHK(bitnet_hip_pack_cols_dev(pf_qkv_, ld, QD, 2 * KD, N, world > 1 ? sp_kv_send_ : sp_kv_all_, wire_f16 ? 1 : 0, s));
-        if (world > 1 && gather(gather_ctx, sp_kv_send_, sp_kv_all_, per_rank, s) != 0) {
-            err_ = "prefill_sharded: the all-gather callback failed";
-            return BITNET_HIP_ERR_EXECUTION;
+        if (world > 1) {
+            // the collective runs on its own stream beside the query-side preparation (RoPE + f16 pack of this rank's q rows);
+            // the k / v slabs and the attention follow once it has finished
+            HCHK(hipEventRecord((hipEvent_t)sp_ev_pack_, s));
+            HCHK(hipStreamWaitEvent((hipStream_t)comm_stream_, (hipEvent_t)sp_ev_pack_, 0));
+            if (gather(gather_ctx, sp_kv_send_, sp_kv_all_, per_rank, comm_stream_) != 0) {
+                err_ = "prefill_sharded: the all-gather callback failed";
+                return BITNET_HIP_ERR_EXECUTION;
+            }
+            HCHK(hipEventRecord((hipEvent_t)sp_ev_gather_, (hipStream_t)comm_stream_));
+            BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
+                                                                 rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, 1, s));
+            HCHK(hipStreamWaitEvent(s, (hipEvent_t)sp_ev_gather_, 0));
         }
-        BCHK(bitnet_hip_attention_prefill_gathered_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
-                                                       rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
+        BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
+                                                             rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_,
+                                                             world > 1 ? 2 : 0, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));

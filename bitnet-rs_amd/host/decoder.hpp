@@ -187,6 +187,7 @@ class Decoder {
     // sharded prefill buffers (grown on demand)
     int sp_cap_ = 0, sp_ctx_ = 0;
     void *sp_kv_send_ = nullptr, *sp_kv_all_ = nullptr;
+    void *comm_stream_ = nullptr, *sp_ev_pack_ = nullptr, *sp_ev_gather_ = nullptr;  // the all-gather's own stream and its two ties to the compute stream
     int32_t *sp_block_pos_ = nullptr, *sp_tokens_ = nullptr;
     // prefill buffers (grown on demand)
     int pf_cap_ = 0;

@@ -425,6 +425,15 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q_dev, size_t ld_q, c
                                               void *vcache_dev, int cache_f16, size_t n_heads, size_t n_kv_heads,
                                               size_t head_dim, size_t max_pos, void *workspace_dev, size_t workspace_bytes,
                                               float *out_dev, void *stream);
+/* The same in two steps, so that the all-gather of k|v can run on ANOTHER stream beside the query-side work: phase 1 prepares the
+ * query slabs only (RoPE, f16; kv_gathered_dev is not read), phase 2 does the k / v slabs, the cache fill and the attention on
+ * the workspace phase 1 left; phase 0 = both (the call above). */
+int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q_dev, size_t ld_q, const int32_t *q_block_pos_dev, size_t n_q,
+                                                    const void *kv_gathered_dev, size_t n_ctx, size_t world, int kv_is_f16,
+                                                    const float *rope_sin_dev, const float *rope_cos_dev, void *kcache_dev,
+                                                    void *vcache_dev, int cache_f16, size_t n_heads, size_t n_kv_heads,
+                                                    size_t head_dim, size_t max_pos, void *workspace_dev, size_t workspace_bytes,
+                                                    float *out_dev, int phase, void *stream);
 int bitnet_hip_pack_cols_dev(const float *src_dev, size_t ld, size_t col0, size_t ncols, size_t rows, void *dst_dev,
                              int as_f16, void *stream);
 /* bytes of scratch_dev attention_decode_dev needs (per-chunk softmax partials) */

@@ -183,7 +183,7 @@ def test_qk256_gemv_batch_dropin(hip, oracle):
 def test_prefill_attention_is_causal_and_block_independent(hip, oracle, torch_):
     """Properties at a long sequence (2,000 tokens, 2B-4T head counts): outputs of positions < t do not
     change when tokens >= t change (bit for bit), and a token-parallel call that only holds the first
-    1,024 queries (64-row blocks in any order) reproduces those rows exactly."""
+    1,024 queries (64-row blocks in any order) reproduces those rows (to the rounding of the key-split merge)."""
     n_heads, n_kv, D, T, max_pos = 20, 5, 128, 2000, 2048
     rng = np.random.default_rng(2000)
     qkv = rng.normal(0, 1.2, (T, (n_heads + 2 * n_kv) * D)).astype(np.float32)
@@ -223,7 +223,8 @@ def test_prefill_attention_is_causal_and_block_independent(hip, oracle, torch_):
     hip.attention_prefill_sharded_dev(q_local, n_heads * D, bp, nq, kv_all, 2 * n_kv * D, T, sin_d, cos_d, kc, vc, n_heads, n_kv, D, max_pos, ws2,
                                       wsb2, out)
     torch_.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), base[rows])
+    # (the two launches split a query block's key tiles over different numbers of workgroups: equal up to the f32 merge's rounding)
+    assert np.max(np.abs(out.cpu().numpy() - base[rows])) <= 1e-3 * np.max(np.abs(base))  # the probabilities are rounded to f16 against each part's own running maximum
 
 
 MANYKV = dict(hidden=1024, n_layers=2, n_heads=8, n_kv_heads=8, head_dim=128, ffn=1024, vocab=2048, max_pos=2176, eps=1e-5, rope_theta=10000.0)
@@ -340,8 +341,8 @@ def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T
 def test_gathered_attention_world8_8k_matches_unsharded_and_f64(hip, oracle, torch_, wire_f16):
     """bitnet_hip_attention_prefill_gathered_dev exactly as the 8-GPU run of BASELINE configs[4] calls it: 8192 positions in 16
     zigzag chunks of 512, the k|v rows in rank-major order as ncclAllGather leaves them (f32, or f16 on the wire), 2B-4T head
-    counts, one rank's 1024 queries per call.  f32 on the wire must reproduce the unsharded kernel's rows bit for bit and fill
-    the same cache; f16 on the wire is held to the f64 reference (the prompt attention rounds k, v to f16 anyway)."""
+    counts, one rank's 1024 queries per call (4 key splits: 640 workgroups).  f32 on the wire must reproduce the unsharded
+    kernel's rows (to the f32 rounding of the key-split merge) and fill the same cache bit for bit; f16 on the wire is held to the f64 reference (the prompt attention rounds k, v to f16 anyway)."""
     n_heads, n_kv, D, T, world, max_pos = 20, 5, 128, 8192, 8, 8192
     chunk, nq, KD = T // (2 * world), T // world, n_kv * 128
     rng = np.random.default_rng(8192)
@@ -377,7 +378,7 @@ def test_gathered_attention_world8_8k_matches_unsharded_and_f64(hip, oracle, tor
         got = out.cpu().numpy()
         assert not np.isnan(got).any()
         if not wire_f16:
-            assert np.array_equal(got, base[rows]), rank
+            assert np.max(np.abs(got - base[rows])) <= 1e-3 * np.max(np.abs(base)), rank  # key splits differ (8 parts here, 1 there): f16 probabilities against each part's own maximum
             assert torch_.equal(kc, kc0) and torch_.equal(vc, vc0), rank  # every rank fills the whole cache
         else:
             assert np.max(np.abs(got - base[rows])) <= 6e-3 and cosine(got, base[rows]) >= 0.99999, rank
