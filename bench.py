@@ -377,7 +377,9 @@ def main():
     ap.add_argument("--gguf", default=None, help="a real model file instead of synthetic weights (default: $BITNET_GGUF if set); the line then says data: gguf")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the token-parallel prefill that normally rides in the same line")
     ap.add_argument("--c5-prompt", type=int, default=8192, help="prompt length of that prefill (a multiple of 128 x N)")
-    ap.add_argument("--kv16", action="store_true", help="opt-in f16 KV cache (half the bytes of the long-context attention stream; the reference's cache is f32)")
+    ap.add_argument("--kv16", action="store_true", help="f16 KV cache (half the bytes of the long-context attention stream; the reference's cache is f32): the default of "
+                    "the long-context workload c4, where the K/V stream outweighs the weights; parity-tested against the oracle at 2k+ keys (tests/test_decode_parity.py)")
+    ap.add_argument("--kv32", action="store_true", help="c4: keep the f32 KV cache (the reference's type, T:1171-1202)")
     ap.add_argument("--exact-act", action="store_true", help="exact f32 activations between the kernels (round 1's path) instead of QAct")
     args = ap.parse_args()
 
@@ -426,7 +428,8 @@ def main():
     cfg, dec, _ = build_model(pkg, synth, args.workload, args.layers, gguf)
     if args.exact_act:
         dec.set_act_mode(0)
-    if args.kv16:
+    kv16 = args.kv16 or (args.workload == "c4" and not args.kv32)
+    if kv16:
         dec.set_kv_f16(True)
     if args.workload == "c5":
         return bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec)
@@ -526,7 +529,7 @@ def main():
                 "kv_len_during_timing": [PROMPT_LEN + 1 + args.warmup, PROMPT_LEN + 1 + args.warmup + args.steps],
                 "parallelism": f"replicas x{n_gpus}" if n_gpus > 1 else "single GPU",
                 "launch": "hipGraph replay per token" if use_graph else "eager",
-                "kv_cache": "f16 (opt-in, rounded once at append)" if args.kv16 else "f32 (as the reference, T:1171-1202)",
+                "kv_cache": "f16 (values rounded once, when appended; --kv32 keeps the reference's f32)" if kv16 else "f32 (as the reference, T:1171-1202)",
             },
             "i2s_matmul_gbs_whole_step": round(i2s_gbs, 1),
             "i2s_matmul_frac_of_hbm_peak_whole_step": round(i2s_gbs / HBM_PEAK_GBS, 4),

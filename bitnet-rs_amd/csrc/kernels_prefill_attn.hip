@@ -127,11 +127,14 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
         }
         __syncthreads();
     }
+    // the softmax scale (and the change to base 2) rides in the f16 image of q: one multiply per query element here instead of
+    // one per score in every key tile
+    const float qmul = is_q ? 1.4426950408889634f * p.scale : 1.0f;
     auto store_rows_f16 = [&](_Float16 *dst) {  // [64 tokens][128] halves, contiguous: 8 bytes per thread and iteration
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i, tok = idx >> 5, d = (idx & 31) * 4;
             const float4 v = *reinterpret_cast<const float4 *>(&tile[tok][d]);
-            const v4h h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const v4h h = {(_Float16)(v.x * qmul), (_Float16)(v.y * qmul), (_Float16)(v.z * qmul), (_Float16)(v.w * qmul)};
             *reinterpret_cast<v4h *>(dst + (size_t)tok * kPD + d) = h;
         }
     };
@@ -258,7 +261,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         m_run[q] = -INFINITY;
         l_run[q] = 0.0f;
     }
-    const float scale_log2 = 1.4426950408889634f * p.scale;  // softmax in base 2
+    // softmax in base 2; the scale is already in q (k_prefill_prep)
+    const int qmin = __builtin_amdgcn_readfirstlane(p.causal ? bpos : p.T - 1);  // lowest key limit of any query of this wave
     const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
     const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
 
@@ -299,38 +303,52 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
             }
         }
         // ---- online softmax for query column c of each group (keys of this lane: 16 i + 4 g + j) ----
+        // Only tiles that reach past some query's limit are masked (the diagonal ones, and the context's last): wave-uniform.
+        const bool need_mask = kt * kQB + kQB - 1 > qmin;
         v8h pb[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             float mt = -INFINITY;
+            if (need_mask) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pos = kt * kQB + 16 * i + 4 * g + j;
-                    const float v = pos <= qlim[q] ? s[q][i][j] * scale_log2 : -INFINITY;  // causal mask (T:452-470) / end of the context
-                    s[q][i][j] = v;
-                    mt = fmaxf(mt, v);
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const int pos = kt * kQB + 16 * i + 4 * g + j;
+                        const float v = pos <= qlim[q] ? s[q][i][j] : -INFINITY;  // causal mask (T:452-470) / end of the context
+                        s[q][i][j] = v;
+                        mt = fmaxf(mt, v);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mt = fmaxf(fmaxf(mt, fmaxf(s[q][i][0], s[q][i][1])), fmaxf(s[q][i][2], s[q][i][3]));
+            }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            // finite: key 0 is visible to every query -- of the FIRST key split; a later split's first tile can lie wholly above a
-            // query's limit (its 64-row block spans several query groups): exp2(-inf - (-inf)) would be NaN, so the shift is clamped
-            const float m_new = fmaxf(fmaxf(m_run[q], mt), -3.0e38f);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
+            // The reference point of the exponentials only moves when the maximum grows by more than 2^8 (the f16 probabilities
+            // then stay <= 256, the sums are f32): most tiles skip the rescaling of the 32 output accumulators.  Finite: key 0 is
+            // visible to every query of the FIRST key split; a later split's first tile can lie wholly above a query's limit (its
+            // 64-row block spans several query groups): the clamp keeps 2^(-inf - -inf) out.
+            const bool grow = mt > m_run[q] + 8.0f || m_run[q] == -INFINITY;  // (the first tile of a part always sets a finite reference)
+            float m_ref = m_run[q];
+            if (__any(grow)) {
+                m_ref = grow ? fmaxf(mt, -3.0e38f) : m_run[q];
+                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_ref);
+                l_run[q] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) o[q][dt] *= alpha;
+                m_run[q] = m_ref;
+            }
             float lsum = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(s[q][i][j] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(s[q][i][j] - m_ref);
                     s[q][i][j] = e;
                     lsum += e;
                 }
-            l_run[q] = l_run[q] * alpha + lsum;
-            m_run[q] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) o[q][dt] *= alpha;
+            l_run[q] += lsum;
             // P^T operand: k-slot (g, j) = key 32u + 4g + j (j < 4), 32u + 16 + 4g + (j - 4)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
