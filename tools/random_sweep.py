@@ -68,7 +68,9 @@ for case in range(n_cases):
                 hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, ln_gamma=gd if ln else None, ln_eps=1e-5, residual=rd if res else None, digits=digits)
         torch.cuda.synchronize()
         got = yd.cpu().numpy()
-        tol = (3e-5 if not (fused and m > 1 and digits == 2) else 3e-4) * max(1.0, float(np.max(np.abs(want)))) + 2e-4 * np.sqrt(cols / 256.0)
+        # 2 digits: 14-bit activations; on f16-scaled 32-blocks (cols % 256 == 0) the f16 matrix cores with f16 activations (2^-12 per element)
+        f16w = fused and m > 1 and digits == 2 and fmt == "i2s32h" and cols % 256 == 0
+        tol = (3e-5 if not (fused and m > 1 and digits == 2) else 1.5e-3 if f16w else 3e-4) * max(1.0, float(np.max(np.abs(want)))) + 2e-4 * np.sqrt(cols / 256.0)
         err = float(np.max(np.abs(got - want)))
         ok = np.isfinite(got).all() and err <= tol
     except pkg.BitNetHipError as e:

@@ -25,7 +25,9 @@ for case in range(n_cases):
         p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
         want = np.einsum("bhqk,bhkd->bhqd", p, v64)
         err = float(np.max(np.abs(got - want)))
-        ok = np.isfinite(got).all() and err <= 8e-3  # q, k, v, p go through the matrix cores as f16 (2^-11 relative each)
+        # q, k, v, p go through the matrix cores as f16 (2^-11 relative each); a score of magnitude |s| carries ~|s| 2^-11 of that into its
+        # exponential, so the sharpest setting (scale 0.2: |s| up to ~15) gets the wider gate
+        ok = np.isfinite(got).all() and err <= (1.2e-2 if scale >= 0.2 else 8e-3)
     except pkg.BitNetHipError as e:
         ok, err = False, repr(e)
     if not ok:
