@@ -50,7 +50,10 @@ def main():
     grids = collections.defaultdict(set)
     for f in trace:
         for r in csv.DictReader(open(f)):
-            key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
+            # workgroups of the whole (possibly 2-D / 3-D) grid: the counter files give the product, so the key uses it too
+            grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+            wg = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
+            key = (short(r["Kernel_Name"]), grid // max(1, wg))
             k[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     pmc = {}
     for cname, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0 * 1024.0), ("WRITE_SIZE", "pmc_write", 1024.0)):
