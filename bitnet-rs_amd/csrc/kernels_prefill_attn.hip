@@ -18,6 +18,8 @@
 // q, k, v and the probabilities are rounded to f16 for the matrix cores (relative 2^-11);
 // the KV cache the decode steps read afterwards is the exact f32 values.
 #include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 
 #include "common.hpp"
 
@@ -30,8 +32,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kPD = 128;       // head dim
 constexpr int kQB = 64;        // keys per tile; query rows come in 64-row blocks (q_block_pos)
 constexpr int kQPad = 128;     // query rows are padded to this (the largest workgroup query tile)
-constexpr int kKPitch = 272;   // bytes per key row in LDS: 128 f16 + 16
-constexpr int kVPitch = 144;   // bytes per dim row in LDS: 64 f16 + 16
+constexpr int kKTile = kQB * kPD * 2;   // one K tile in LDS: 64 keys x 256 bytes, unpadded; 16-byte unit u of key r sits at u ^ (r & 15)
+constexpr int kVTile = kPD * kQB * 2;   // one V^T tile: 128 dims x 128 bytes; unit u of dim r sits at u ^ ((r >> 1) & 7)
+constexpr int kKVBuf = kKTile + kVTile; // the kernel keeps two (tile t + 1 lands while tile t is multiplied)
 constexpr int kTilesPerSplit = 16;  // key split (PrefillArgs::ksplit): key tiles one workgroup walks at least before a block is cut
 
 struct PrefillArgs {
@@ -198,15 +201,25 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
 // are pinned one chunk ahead of their MFMAs (hipcc's own schedule waited for every read right before its MFMAs).
 typedef unsigned pv4u __attribute__((ext_vector_type(4)));
 
+// LDS-DMA: 64 lanes x 16 B from (scalar base + per-lane byte offset) to LDS bytes [lds_dst, lds_dst + 1024).  Invisible to hipcc's
+// vmcnt bookkeeping (cdna_hip_programming.md 5.7): the kernel waits with explicit s_waitcnt vmcnt(0) and issues no other vector
+// memory loads while these are in flight.
+__device__ __forceinline__ void gdma1k_s(unsigned lane_off, const void *sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 template <int HW, int NW, int NQ>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(PrefillArgs p) {
     constexpr int QW = NW / HW, QG = 16 * QW * NQ;  // wave columns per workgroup, queries per workgroup
-    constexpr int NT = NW * 64, NLD = 1024 / NT;
-    __shared__ __attribute__((aligned(16))) uint8_t ks[kQB * kKPitch];
-    __shared__ __attribute__((aligned(16))) uint8_t vs[kPD * kVPitch];
+    static_assert(NW == 4, "tile staging deals 32 pieces to 4 waves");
+    extern __shared__ __attribute__((aligned(16))) uint8_t kv_lds[];  // [2][K tile | V^T tile]
     __shared__ int s_last;
     const int qg = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
     const int h = blockIdx.y * HW + wave % HW, kvh = h / (p.n_heads / p.n_kv);  // HW divides the group: one KV head per workgroup
     const int qbase = qg * QG + (wave / HW) * 16 * NQ;            // first query row of this wave (16 NQ rows inside one 64-row block)
     const int blk64 = qbase >> 6;                                 // the 64-row block the wave's rows lie in
@@ -263,36 +276,60 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     }
     // softmax in base 2; the scale is already in q (k_prefill_prep)
     const int qmin = __builtin_amdgcn_readfirstlane(p.causal ? bpos : p.T - 1);  // lowest key limit of any query of this wave
-    const _Float16 *kbase = p.kh + (size_t)kvh * p.Tpad * kPD;
-    const _Float16 *vbase = p.vt + (size_t)kvh * kPD * p.Tpad;
+    const uint8_t *kbase = reinterpret_cast<const uint8_t *>(p.kh + (size_t)kvh * p.Tpad * kPD);
+    const uint8_t *vbase = reinterpret_cast<const uint8_t *>(p.vt + (size_t)kvh * kPD * p.Tpad);
+    // Tile staging by LDS-DMA: a K tile is 16 pieces of 1 KiB (4 keys), a V^T tile 16 pieces (8 dim rows x 128 B); wave w moves
+    // pieces 4 w .. 4 w + 3 of each.  A lane fetches the 16-byte unit that belongs at ITS slot of the piece (the XOR swizzles
+    // above), so the unpadded tiles read conflict-free.  Byte offsets from the tile's first byte (scalar base):
+    unsigned ksrc[4], vsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = 4 * (4 * wave + i) + (lane >> 4), dim = 8 * (4 * wave + i) + (lane >> 3);
+        ksrc[i] = (unsigned)(key * 256 + (((lane & 15) ^ (key & 15)) * 16));
+        vsrc[i] = (unsigned)dim * (unsigned)(p.Tpad * 2) + (unsigned)((((lane & 7) ^ ((dim >> 1) & 7))) * 16);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)kv_lds;
+    auto stage = [&](int kt, int buf) {
+        const uint8_t *kt_k = kbase + (size_t)kt * kKTile;
+        const uint8_t *kt_v = vbase + (size_t)kt * (kQB * 2);
+        const unsigned dst = lds0 + (unsigned)buf * kKVBuf + (unsigned)(4 * wave) * 1024u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gdma1k_s(ksrc[i], kt_k, dst + 1024u * i);
+            gdma1k_s(vsrc[i], kt_v, dst + kKTile + 1024u * i);
+        }
+    };
+    // operand read offsets inside a tile (+ 4096 i per key tile of 16, + 2048 dt per dim tile of 16: immediates)
+    const unsigned kro = (unsigned)(c * 256 + ((g ^ c) * 16));                               // ^ (64 ch): unit 4 ch + g of key c
+    const unsigned vro = (unsigned)(c * 128 + ((((g >> 1) ^ (c >> 1))) * 16) + 8 * (g & 1)); // ^ (64 u + 32 hi): unit 4 u + 2 hi + (g >> 1)
+    stage(kt_first, 0);
+    if (kt_first < kt_last) stage(kt_first + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     for (int kt = kt_first; kt <= kt_last; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + NT * i;
-            *reinterpret_cast<pv4u *>(ks + (idx >> 4) * kKPitch + (idx & 15) * 16) =
-                *reinterpret_cast<const pv4u *>(kbase + ((size_t)(kt * kQB + (idx >> 4))) * kPD + (idx & 15) * 8);  // K tile: 64 keys x 128 dims
-            *reinterpret_cast<pv4u *>(vs + (idx >> 3) * kVPitch + (idx & 7) * 16) =
-                *reinterpret_cast<const pv4u *>(vbase + (size_t)(idx >> 3) * p.Tpad + kt * kQB + (idx & 7) * 8);    // V^T tile: 128 dims x 64 keys
-        }
-        __syncthreads();
-        // ---- S^T = K Q^T: 4 key tiles of 16, reduced over 4 dim chunks of 32; one operand read per NQ MFMAs ----
+        const uint8_t *ks = kv_lds + ((kt - kt_first) & 1) * kKVBuf, *vs = ks + kKTile;
+        // ---- S^T = K Q^T - m: 4 key tiles of 16, reduced over 4 dim chunks of 32; one operand read per NQ MFMAs.  The accumulators
+        // start at minus the running reference point, so the common tile (reference unchanged) exponentiates them as they are ----
         v4f s[NQ][4];
+        float m_init[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q) {
+            m_init[q] = m_run[q] < -1.0e30f ? 0.0f : m_run[q];  // no reference yet (first tile, or only masked keys so far)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[q][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) s[q][i] = (v4f){-m_init[q], -m_init[q], -m_init[q], -m_init[q]};
+        }
         {
             v8h ab[2][4];
-            const uint8_t *kp = ks + c * kKPitch + 16 * g;
+            const uint8_t *kp = ks + kro;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ab[0][i] = *reinterpret_cast<const v8h *>(kp + 16 * i * kKPitch);
+            for (int i = 0; i < 4; ++i) ab[0][i] = *reinterpret_cast<const v8h *>(kp + 4096 * i);
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 if (ch < 3) {
+                    const uint8_t *kn = ks + (kro ^ (unsigned)(64 * (ch + 1)));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ab[(ch + 1) & 1][i] = *reinterpret_cast<const v8h *>(kp + 16 * i * kKPitch + 64 * (ch + 1));
+                    for (int i = 0; i < 4; ++i) ab[(ch + 1) & 1][i] = *reinterpret_cast<const v8h *>(kn + 4096 * i);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // the reads above stay above these MFMAs
 #pragma unroll
@@ -325,26 +362,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
             }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            // The reference point of the exponentials only moves when the maximum grows by more than 2^8 (the f16 probabilities
-            // then stay <= 256, the sums are f32): most tiles skip the rescaling of the 32 output accumulators.  Finite: key 0 is
-            // visible to every query of the FIRST key split; a later split's first tile can lie wholly above a query's limit (its
-            // 64-row block spans several query groups): the clamp keeps 2^(-inf - -inf) out.
-            const bool grow = mt > m_run[q] + 8.0f || m_run[q] == -INFINITY;  // (the first tile of a part always sets a finite reference)
-            float m_ref = m_run[q];
+            // mt is relative to the running reference.  The reference only moves when the maximum outgrows it by more than 2^8 (the
+            // f16 probabilities then stay <= 256, the sums are f32): most tiles skip both the shift of the scores and the rescaling
+            // of the 32 output accumulators.  A tile wholly above a query's limit (a later key split's first tile: its 64-row block
+            // spans several query groups) leaves mt = -inf: the clamp keeps 2^(-inf - -inf) out and the reference stays "unset".
+            const bool unset = m_run[q] < -1.0e30f;
+            const bool grow = mt > 8.0f || unset;
             if (__any(grow)) {
-                m_ref = grow ? fmaxf(mt, -3.0e38f) : m_run[q];
-                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_ref);
+                const float shift = grow ? fmaxf(mt, -3.0e38f) : 0.0f;
+                const float m_new = unset ? shift : m_run[q] + shift;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
                 l_run[q] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) o[q][dt] *= alpha;
-                m_run[q] = m_ref;
+                m_run[q] = m_new;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[q][i][j] -= shift;
             }
             float lsum = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(s[q][i][j] - m_ref);
+                    const float e = __builtin_amdgcn_exp2f(s[q][i][j]);
                     s[q][i][j] = e;
                     lsum += e;
                 }
@@ -361,10 +403,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         // ---- O^T += V^T P^T: operand reads four dim tiles ahead ----
         {
             v8h vb[2][4];
-            const uint8_t *vp0 = vs + c * kVPitch + 8 * g;
             auto vread = [&](int u, int dt) {
-                const uint8_t *vp = vp0 + 16 * dt * kVPitch + 64 * u;
-                const v4h lo = *reinterpret_cast<const v4h *>(vp), hi = *reinterpret_cast<const v4h *>(vp + 32);
+                const uint8_t *vp = vs + (vro ^ (unsigned)(64 * u)) + 2048 * dt;
+                const v4h lo = *reinterpret_cast<const v4h *>(vp), hi = *reinterpret_cast<const v4h *>(vs + (vro ^ (unsigned)(64 * u + 32)) + 2048 * dt);
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             };
 #pragma unroll
@@ -385,6 +426,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // tile kt + 1 (requested one tile ago) has landed; every wave is done with this buffer, which takes tile kt + 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 <= kt_last) stage(kt + 2, (kt - kt_first) & 1);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -447,17 +492,36 @@ static int attn_ksplit(int n_heads, int n_kv, int nq_pad, int T) {
     return s < 1 ? 1 : s > 8 ? 8 : s;
 }
 
-static void launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
+static hipError_t launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
     const int group = p.n_heads / p.n_kv;
     const unsigned z = (unsigned)p.ksplit;
-    if (group % 4 == 0)  // 4 waves = the 4 heads of a KV head x 32 queries each; two such workgroups per CU
-        hipLaunchKernelGGL((k_prefill_attn<4, 4, 2>), dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4), z), dim3(256), 0, stream, p);
-    else if (group % 2 == 0)  // 2 heads x 2 wave columns x 32 queries
-        hipLaunchKernelGGL((k_prefill_attn<2, 4, 2>), dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2), z), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((k_prefill_attn<1, 4, 2>), dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads, z), dim3(256), 0, stream, p);
+    void (*ak)(PrefillArgs);
+    dim3 grid;
+    if (group % 4 == 0) {  // 4 waves = the 4 heads of a KV head x 32 queries each; two such workgroups per CU
+        ak = k_prefill_attn<4, 4, 2>;
+        grid = dim3((unsigned)(p.nq_pad / 32), (unsigned)(p.n_heads / 4), z);
+    } else if (group % 2 == 0) {  // 2 heads x 2 wave columns x 32 queries
+        ak = k_prefill_attn<2, 4, 2>;
+        grid = dim3((unsigned)(p.nq_pad / 64), (unsigned)(p.n_heads / 2), z);
+    } else {
+        ak = k_prefill_attn<1, 4, 2>;
+        grid = dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads, z);
+    }
+    {
+        // two tile buffers = 64 KiB of dynamic LDS (+ a static word): raised once per kernel; entry points may run concurrently
+        static std::mutex raised_mu;
+        static std::unordered_set<const void *> raised;
+        std::lock_guard<std::mutex> lk(raised_mu);
+        if (!raised.count((const void *)ak)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ak), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kKVBuf);
+            if (e != hipSuccess) return e;
+            raised.insert((const void *)ak);
+        }
+    }
+    hipLaunchKernelGGL(ak, grid, dim3(256), 2 * kKVBuf, stream, p);
     if (p.ksplit > 1)
         hipLaunchKernelGGL(k_prefill_merge, dim3((unsigned)div_ceil((size_t)p.nq * p.n_heads * 32, 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 static size_t attn_f16_bytes(int n_heads, int n_kv, size_t qpad, size_t tpad) {
@@ -523,8 +587,7 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
-    launch_attn_kernel(p, stream);
-    return hipGetLastError();
+    return launch_attn_kernel(p, stream);
 }
 
 // rows x [col0, col0 + ncols) of a row-major f32 matrix -> a compact [rows, ncols] buffer, f32 or f16: the k|v columns of the
@@ -583,8 +646,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     const unsigned nb = (unsigned)(p.nq_pad / kQB);
     hipLaunchKernelGGL(k_prefill_prep, dim3(nb, (unsigned)(3 * n_heads)), dim3(256), 0, stream, p);
-    launch_attn_kernel(p, stream);
-    return hipGetLastError();
+    return launch_attn_kernel(p, stream);
 }
 
 }  // namespace bitnet_hip
