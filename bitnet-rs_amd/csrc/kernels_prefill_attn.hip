@@ -33,7 +33,7 @@ constexpr int kPD = 128;       // head dim
 constexpr int kQB = 64;        // keys per tile; query rows come in 64-row blocks (q_block_pos)
 constexpr int kQPad = 128;     // query rows are padded to this (the largest workgroup query tile)
 constexpr int kKTile = kQB * kPD * 2;   // one K tile in LDS: 64 keys x 256 bytes, unpadded; 16-byte unit u of key r sits at u ^ (r & 15)
-constexpr int kVTile = kPD * kQB * 2;   // one V^T tile: 128 dims x 128 bytes; unit u of dim r sits at u ^ ((r >> 1) & 7)
+constexpr int kVTile = kPD * kQB * 2;   // one V^T tile: 128 dims x 128 bytes (keys in operand order, k_prefill_prep); unit u of dim r sits at u ^ ((r >> 1) & 7)
 constexpr int kKVBuf = kKTile + kVTile; // the kernel keeps two (tile t + 1 lands while tile t is multiplied)
 constexpr int kTilesPerSplit = 16;  // key split (PrefillArgs::ksplit): key tiles one workgroup walks at least before a block is cut
 
@@ -181,11 +181,15 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
                 if (t0 + tok < p.T) *reinterpret_cast<float4 *>(vc + (size_t)(t0 + tok) * kPD + d) = *reinterpret_cast<const float4 *>(&tile[tok][d]);
             }
         }
-        _Float16 *vt = p.vt + (size_t)kvh * kPD * p.Tpad;  // [128][Tpad]: 4 adjacent positions of one dim = 8 contiguous bytes
+        // [128][Tpad], the keys of every group of 32 in the order the second product's operand wants them: key 4 a + 16 b + j
+        // (a < 4, b < 2, j < 4) at slot 8 a + 4 b + j, so that a lane's 8 k-slots (keys 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3: the
+        // S^T accumulator layout) are ONE 16-byte unit.  4 adjacent positions of one dim = 8 contiguous bytes here as well.
+        _Float16 *vt = p.vt + (size_t)kvh * kPD * p.Tpad;
         for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, d = idx >> 4, tok = (idx & 15) * 4;
+            const int idx = tid + 256 * i, d = idx >> 4, t4 = idx & 15, tok = t4 * 4;
+            const int slot = 32 * (t4 >> 3) + 8 * (t4 & 3) + 4 * ((t4 >> 2) & 1);
             const v4h h = {(_Float16)tile[tok][d], (_Float16)tile[tok + 1][d], (_Float16)tile[tok + 2][d], (_Float16)tile[tok + 3][d]};
-            *reinterpret_cast<v4h *>(vt + (size_t)d * p.Tpad + t0 + tok) = h;
+            *reinterpret_cast<v4h *>(vt + (size_t)d * p.Tpad + t0 + slot) = h;
         }
     }
 }
@@ -200,6 +204,13 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
 // while the other multiplies).  The next key tile is requested into registers one iteration ahead and the LDS operand reads
 // are pinned one chunk ahead of their MFMAs (hipcc's own schedule waited for every read right before its MFMAs).
 typedef unsigned pv4u __attribute__((ext_vector_type(4)));
+
+// max of three without the v_max(x, x) canonicalisation hipcc puts in front of every fmaxf of an MFMA result (no NaNs here)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // LDS-DMA: 64 lanes x 16 B from (scalar base + per-lane byte offset) to LDS bytes [lds_dst, lds_dst + 1024).  Invisible to hipcc's
 // vmcnt bookkeeping (cdna_hip_programming.md 5.7): the kernel waits with explicit s_waitcnt vmcnt(0) and issues no other vector
@@ -289,26 +300,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         vsrc[i] = (unsigned)dim * (unsigned)(p.Tpad * 2) + (unsigned)((((lane & 7) ^ ((dim >> 1) & 7))) * 16);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)kv_lds;
-    auto stage = [&](int kt, int buf) {
-        const uint8_t *kt_k = kbase + (size_t)kt * kKTile;
-        const uint8_t *kt_v = vbase + (size_t)kt * (kQB * 2);
+    auto stage_k = [&](int kt, int buf) {
+        const uint8_t *src = kbase + (size_t)kt * kKTile;
         const unsigned dst = lds0 + (unsigned)buf * kKVBuf + (unsigned)(4 * wave) * 1024u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gdma1k_s(ksrc[i], kt_k, dst + 1024u * i);
-            gdma1k_s(vsrc[i], kt_v, dst + kKTile + 1024u * i);
-        }
+        for (int i = 0; i < 4; ++i) gdma1k_s(ksrc[i], src, dst + 1024u * i);
+    };
+    auto stage_v = [&](int kt, int buf) {
+        const uint8_t *src = vbase + (size_t)kt * (kQB * 2);
+        const unsigned dst = lds0 + (unsigned)buf * kKVBuf + kKTile + (unsigned)(4 * wave) * 1024u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gdma1k_s(vsrc[i], src, dst + 1024u * i);
     };
     // operand read offsets inside a tile (+ 4096 i per key tile of 16, + 2048 dt per dim tile of 16: immediates)
     const unsigned kro = (unsigned)(c * 256 + ((g ^ c) * 16));                               // ^ (64 ch): unit 4 ch + g of key c
-    const unsigned vro = (unsigned)(c * 128 + ((((g >> 1) ^ (c >> 1))) * 16) + 8 * (g & 1)); // ^ (64 u + 32 hi): unit 4 u + 2 hi + (g >> 1)
-    stage(kt_first, 0);
-    if (kt_first < kt_last) stage(kt_first + 1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned vro = (unsigned)(c * 128 + ((g ^ (c >> 1)) * 16));                         // ^ (64 u): unit 4 u + g of dim c
+    // The MFMA operands of a tile form one stream of 8 chunks (K dims 0-31 .. 96-127, then V^T (keys 0-31, dims 0-63), (0-31, 64-127),
+    // (32-63, 0-63), (32-63, 64-127)), 4 operands of 1 KiB per wave each; chunk j's LDS reads are issued TWO chunks ahead of its
+    // MFMAs, across the softmax and across the tile boundary (hipcc's own schedule waited for every read right before its MFMAs;
+    // one chunk ahead still left the waves waiting: the reads' latency, not LDS bandwidth, was what the kernel stood on).
+    v8h ring[4][4];
+    auto kread = [&](int slot, int ch, const uint8_t *ks) {
+        const uint8_t *kp = ks + (kro ^ (unsigned)(64 * ch));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[slot][i] = *reinterpret_cast<const v8h *>(kp + 4096 * i);
+    };
+    auto vread = [&](int slot, int st, const uint8_t *vs) {
+        const uint8_t *vp = vs + (vro ^ (unsigned)(64 * (st >> 1))) + 2048 * 4 * (st & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[slot][i] = *reinterpret_cast<const v8h *>(vp + 2048 * i);
+    };
+    // Staging: K and V^T tiles have separate double buffers and separate schedules, each requested a whole tile ahead of its first
+    // read.  Two barriers per tile: B1 (before the K chunk 2 MFMAs = before the first V read of this tile is issued) waits for
+    // V(kt) and requests V(kt + 1) into the buffer V(kt - 1) left (every wave is past chunk 1 of tile kt: done with tile kt - 1);
+    // B2 (before the V chunk 2 MFMAs = before the first K read of the NEXT tile is issued) waits for K(kt + 1) and requests K(kt + 2)
+    // into the buffer K(kt) left (its last read was issued two chunks ago and consumed by K chunk 3).  Loads return in order, so
+    // "the 4 pieces requested last may still be in flight" is s_waitcnt vmcnt(4).
+    stage_k(kt_first, 0);
+    stage_v(kt_first, 0);
+    if (kt_first < kt_last) stage_k(kt_first + 1, 1);
+    // the builtin form, so that hipcc's own bookkeeping sees its q loads retired here: left to itself it re-waits for them with
+    // s_waitcnt vmcnt(0..7) in front of the MFMAs of EVERY iteration -- which, in hardware, waits for the tile requests it cannot see
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("" ::: "memory");
     __syncthreads();
+    kread(0, 0, kv_lds);
+    kread(1, 1, kv_lds);
 
     for (int kt = kt_first; kt <= kt_last; ++kt) {
-        const uint8_t *ks = kv_lds + ((kt - kt_first) & 1) * kKVBuf, *vs = ks + kKTile;
+        const int par = (kt - kt_first) & 1;
+        const uint8_t *ks = kv_lds + par * kKVBuf, *vs = ks + kKTile, *ks_next = kv_lds + (par ^ 1) * kKVBuf;
+        const bool more = kt < kt_last;  // workgroup-uniform
         // ---- S^T = K Q^T - m: 4 key tiles of 16, reduced over 4 dim chunks of 32; one operand read per NQ MFMAs.  The accumulators
         // start at minus the running reference point, so the common tile (reference unchanged) exponentiates them as they are ----
         v4f s[NQ][4];
@@ -319,25 +361,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[q][i] = (v4f){-m_init[q], -m_init[q], -m_init[q], -m_init[q]};
         }
-        {
-            v8h ab[2][4];
-            const uint8_t *kp = ks + kro;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ab[0][i] = *reinterpret_cast<const v8h *>(kp + 4096 * i);
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                if (ch < 3) {
-                    const uint8_t *kn = ks + (kro ^ (unsigned)(64 * (ch + 1)));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ab[(ch + 1) & 1][i] = *reinterpret_cast<const v8h *>(kn + 4096 * i);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // the reads above stay above these MFMAs
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) s[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab[ch & 1][i], qreg[q][ch], s[q][i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch == 2) {  // B1
+                if (more)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (more) stage_v(kt + 1, par ^ 1);
             }
+            if (ch < 2)
+                kread((ch + 2) & 3, ch + 2, ks);
+            else
+                vread((ch + 2) & 3, ch - 2, vs);
+            __builtin_amdgcn_sched_barrier(0);  // the reads above stay above these MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) s[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ch][i], qreg[q][ch], s[q][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- online softmax for query column c of each group (keys of this lane: 16 i + 4 g + j) ----
         // Only tiles that reach past some query's limit are masked (the diagonal ones, and the context's last): wave-uniform.
@@ -358,7 +401,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
                     }
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mt = fmaxf(fmaxf(mt, fmaxf(s[q][i][0], s[q][i][1])), fmaxf(s[q][i][2], s[q][i][3]));
+                for (int i = 0; i < 4; ++i) mt = max3_raw(max3_raw(mt, s[q][i][0], s[q][i][1]), s[q][i][2], s[q][i][3]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
@@ -400,36 +443,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
                     pb[q][u][4 + j] = (_Float16)s[q][2 * u + 1][j];
                 }
         }
-        // ---- O^T += V^T P^T: operand reads four dim tiles ahead ----
-        {
-            v8h vb[2][4];
-            auto vread = [&](int u, int dt) {
-                const uint8_t *vp = vs + (vro ^ (unsigned)(64 * u)) + 2048 * dt;
-                const v4h lo = *reinterpret_cast<const v4h *>(vp), hi = *reinterpret_cast<const v4h *>(vs + (vro ^ (unsigned)(64 * u + 32)) + 2048 * dt);
-                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            };
+        // ---- O^T += V^T P^T ----
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[0][i] = vread(0, i);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {  // step = (u, half of the dim tiles)
-                const int u = st >> 1, d0 = 4 * (st & 1);
-                if (st < 3) {
-                    const int un = (st + 1) >> 1, dn = 4 * ((st + 1) & 1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) vb[(st + 1) & 1][i] = vread(un, dn + i);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) o[q][d0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[st & 1][i], pb[q][u], o[q][d0 + i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int st = 0; st < 4; ++st) {  // step = (u, half of the dim tiles)
+            const int u = st >> 1, d0 = 4 * (st & 1);
+            if (st == 2) {  // B2
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __syncthreads();
+                if (kt + 2 <= kt_last) stage_k(kt + 2, par);
             }
+            if (st < 2)
+                vread(st + 2, st + 2, vs);
+            else if (more)
+                kread(st - 2, st - 2, ks_next);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) o[q][d0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[st][i], pb[q][u], o[q][d0 + i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // tile kt + 1 (requested one tile ago) has landed; every wave is done with this buffer, which takes tile kt + 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 2 <= kt_last) stage(kt + 2, (kt - kt_first) & 1);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
