@@ -211,6 +211,15 @@ __device__ __forceinline__ float combine_digits(const v4i *acc, int j) {
 // MINW = 4 waves per SIMD = two workgroups per CU (<= 128 registers): the narrow-token-tile form for launches whose wide-tile grid would
 // leave most CUs idle in its last round (a 2560-row matrix x 4096 tokens = 320 wide workgroups on 256 CUs).
 typedef unsigned gv4u __attribute__((ext_vector_type(4)));
+typedef float gv4f __attribute__((ext_vector_type(4)));
+
+// Output rows are written once and read by the NEXT kernel: stored non-temporal, they stop evicting the activation tiles and
+// weight slabs the K loops of the other workgroups are re-reading from L2 (4096 x 13824 outputs = 226 MB through 8 x 4 MB of L2).
+// Measured (tools/perf_gemm_ksweep.py): the launch's time over K is a line whose intercept is the stores' -- 80 -> 59 us at 13824
+// rows, 15.5 -> 10.3 at 2560 -- gate|up 299 -> 275 us, q|k|v 98 -> 93, o 78 -> 73, down 177 -> 172 (quantiser included).
+__device__ __forceinline__ void store_out4(float *dst, float a, float b, float c, float d) {
+    __builtin_nontemporal_store((gv4f){a, b, c, d}, reinterpret_cast<gv4f *>(dst));
+}
 
 // CW = wave columns: 2 (8 waves, 256 rows x 2 TTW token tiles) or 1 (4 waves, 256 rows x TTW token tiles; with MINW = 2 two such
 // workgroups share a CU with independent barriers at the full register budget).
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
                         const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
                         o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
                     }
-                    *reinterpret_cast<float4 *>(p.y + off) = o;
+                    store_out4(p.y + off, o.x, o.y, o.z, o.w);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -542,10 +551,18 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
             for (int pr = 0; pr < 2; ++pr) {
                 const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
                 const size_t off = (size_t)token * half_rows + row0;
+                float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    if (row0 + j < half_rows) p.y[off + j] = gv / (1.0f + expf(-gv)) * uv;
+                    r[j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+                if (row0 + 3 < half_rows && (half_rows & 3) == 0) {
+                    store_out4(p.y + off, r[0], r[1], r[2], r[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + j < half_rows) p.y[off + j] = r[j];
                 }
             }
         }
@@ -774,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
                         const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
                         o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
                     }
-                    *reinterpret_cast<float4 *>(p.y + off) = o;
+                    store_out4(p.y + off, o.x, o.y, o.z, o.w);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -787,10 +804,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
             for (int pr = 0; pr < 2; ++pr) {
                 const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
                 const size_t off = (size_t)token * half_rows + row0;
+                float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    if (row0 + j < half_rows) p.y[off + j] = gv / (1.0f + expf(-gv)) * uv;
+                    r[j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+                if (row0 + 3 < half_rows && (half_rows & 3) == 0) {
+                    store_out4(p.y + off, r[0], r[1], r[2], r[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + j < half_rows) p.y[off + j] = r[j];
                 }
             }
         }
