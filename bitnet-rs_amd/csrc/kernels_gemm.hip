@@ -221,6 +221,76 @@ __device__ __forceinline__ void store_out4(float *dst, float a, float b, float c
     __builtin_nontemporal_store((gv4f){a, b, c, d}, reinterpret_cast<gv4f *>(dst));
 }
 
+// The epilogue's stores.  A lane (c = token of its 16-token group, g) holds val[rt][j] = output row 16 (tile0 + rt) + 4 g + j of its
+// token: one row tile is 64 contiguous bytes per token, so a store instruction per row tile writes HALF lines (non-temporal, not
+// merged in L2: WRITE_SIZE read 158 MB for 113 MB of gate|up outputs).  Row tiles are therefore stored in PAIRS: the odd tile's values
+// move to the lane 8 tokens away (DPP row_ror:8, same g), and each of the pair's two instructions writes whole 128-byte lines --
+// tokens 0-7 (lanes c < 8: their even tile; lanes c >= 8: the odd tile of token c - 8), then tokens 8-15 likewise.
+__device__ __forceinline__ float gdpp_ror8(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+}
+// a / b: this lane's four values of rows ra .. ra + 3 / ra + 16 .. ra + 19 (ra includes 4 g) of token tok0 + c; ld = row length of y
+__device__ __forceinline__ void store_tile_pair(float *y, const float *residual, int ld, int m, int tok0, int c, int ra, const float (&a)[4], const float (&b)[4]) {
+    float rot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rot[j] = gdpp_ror8(b[j]);
+    const bool lo = c < 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {  // tokens 0-7, then 8-15 of the group
+        const bool own = lo == (hh == 0);
+        const int token = tok0 + 8 * hh + (c & 7), row = own ? ra : ra + 16;
+        if (token < m && row + 3 < ld) {
+            const size_t off = (size_t)token * ld + row;
+            float o0 = own ? a[0] : rot[0], o1 = own ? a[1] : rot[1], o2 = own ? a[2] : rot[2], o3 = own ? a[3] : rot[3];
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4 *>(residual + off);
+                o0 += r.x, o1 += r.y, o2 += r.z, o3 += r.w;
+            }
+            store_out4(y + off, o0, o1, o2, o3);
+        }
+    }
+}
+// the whole epilogue of one 16-token group of a wave: val = the lane's 4 row tiles x 4 rows, already scaled; tile0 = first row tile
+__device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)[4][4], int tok0, int c, int g, int tile0) {
+    const int token = tok0 + c;
+    if (!p.silu_mul) {
+        if ((p.rows & 3) == 0) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) store_tile_pair(p.y, p.residual, p.rows, p.m, tok0, c, 16 * (tile0 + 2 * pp) + 4 * g, val[2 * pp], val[2 * pp + 1]);
+        } else if (token < p.m) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int row0 = 16 * (tile0 + rt) + 4 * g;
+                const size_t off = (size_t)token * p.rows + row0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row0 + j < p.rows) p.y[off + j] = val[rt][j] + (p.residual ? p.residual[off + j] : 0.0f);
+            }
+        }
+    } else {
+        // row tiles alternate (gate, up): FeedForward::forward T:756-781, silu(v) = v / (1 + exp(-v))
+        const int half_rows = p.rows >> 1;
+        float r[2][4];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
+                r[pr][j] = gv / (1.0f + expf(-gv)) * uv;
+            }
+        const int ra = 16 * (tile0 >> 1) + 4 * g;  // tile0 / 2 = the wave's first tile of the [m, rows / 2] output
+        if ((half_rows & 3) == 0) {
+            store_tile_pair(p.y, nullptr, half_rows, p.m, tok0, c, ra, r[0], r[1]);
+        } else if (token < p.m) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ra + 16 * pr + j < half_rows) p.y[(size_t)token * half_rows + ra + 16 * pr + j] = r[pr][j];
+        }
+    }
+}
+
 // CW = wave columns: 2 (8 waves, 256 rows x 2 TTW token tiles) or 1 (4 waves, 256 rows x TTW token tiles; with MINW = 2 two such
 // workgroups share a CU with independent barriers at the full register budget).
 template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2>
@@ -515,57 +585,17 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
         }
     }
 
-    // ---- epilogue: digits -> f32, x 2^(E_t - S), [residual | silu*mul], store ------------------
+    // ---- epilogue: digits -> f32, x 2^(E_t - S), [residual | silu*mul], store (whole lines: store_wave_tiles) -----------------------
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
-        const int token = (by * CW * TTW + cw * TTW + tt) * 16 + c;
-        if (token >= p.m) continue;
-        const float is = p.inv_scale[token];
+        const int tok0 = (by * CW * TTW + cw * TTW + tt) * 16;
+        const float is = p.inv_scale[tok0 + c];  // (padding rows: 0)
         float val[4][4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[rt][j] = (WS ? facc[rt][tt][j] : combine_digits<NDIG>(&acc[rt][tt * NDIG], j)) * is;
-        if (!p.silu_mul) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                const int row0 = 16 * (bx * 16 + rw * 4 + rt) + 4 * g;
-                const size_t off = (size_t)token * p.rows + row0;
-                if (row0 + 3 < p.rows && (p.rows & 3) == 0) {
-                    float4 o = {val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
-                    if (p.residual) {
-                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
-                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
-                    }
-                    store_out4(p.y + off, o.x, o.y, o.z, o.w);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (row0 + j < p.rows) p.y[off + j] = val[rt][j] + (p.residual ? p.residual[off + j] : 0.0f);
-                }
-            }
-        } else {
-            // row tiles alternate (gate, up): FeedForward::forward T:756-781, silu(v) = v / (1 + exp(-v))
-            const int half_rows = p.rows >> 1;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
-                const size_t off = (size_t)token * half_rows + row0;
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    r[j] = gv / (1.0f + expf(-gv)) * uv;
-                }
-                if (row0 + 3 < half_rows && (half_rows & 3) == 0) {
-                    store_out4(p.y + off, r[0], r[1], r[2], r[3]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (row0 + j < half_rows) p.y[off + j] = r[j];
-                }
-            }
-        }
+        store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
     }
 }
 
@@ -772,53 +802,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
     // ---- epilogue: x 2^E_t, [residual | silu * mul], store (k_gemm_mfma's) ------------------------------------------------------------
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
-        const int token = (by * TTW + tt) * 16 + c;
-        if (token >= p.m) continue;
-        const float is = p.inv_scale[token];
+        const int tok0 = (by * TTW + tt) * 16;
+        const float is = p.inv_scale[tok0 + c];
         float val[4][4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
-        if (!p.silu_mul) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                const int row0 = 16 * (bx * 16 + rw * 4 + rt) + 4 * g;
-                const size_t off = (size_t)token * p.rows + row0;
-                if (row0 + 3 < p.rows && (p.rows & 3) == 0) {
-                    float4 o = {val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
-                    if (p.residual) {
-                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
-                        o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
-                    }
-                    store_out4(p.y + off, o.x, o.y, o.z, o.w);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (row0 + j < p.rows) p.y[off + j] = val[rt][j] + (p.residual ? p.residual[off + j] : 0.0f);
-                }
-            }
-        } else {
-            const int half_rows = p.rows >> 1;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int row0 = 16 * (bx * 8 + rw * 2 + pr) + 4 * g;
-                const size_t off = (size_t)token * half_rows + row0;
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    r[j] = gv / (1.0f + expf(-gv)) * uv;
-                }
-                if (row0 + 3 < half_rows && (half_rows & 3) == 0) {
-                    store_out4(p.y + off, r[0], r[1], r[2], r[3]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (row0 + j < half_rows) p.y[off + j] = r[j];
-                }
-            }
-        }
+        store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
     }
 }
 
