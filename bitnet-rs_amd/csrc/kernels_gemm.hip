@@ -816,6 +816,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
 // ---- host side ---------------------------------------------------------------------------------
 constexpr size_t kGemmCUs = 256;
 thread_local GemmTileChoice g_last_gemm_tile;  // what the last launch on this thread ran (bitnet_hip_matmul_last_tile)
+// Token tiles (of 16) per wave of the 4-wave 2-digit / f16 forms: 4 (64 tokens) unless
+//  (a) the grid would not cover the chip twice (a short prompt, or one rank's share of a token-parallel prefill: 1024 rows x 2560
+//      output rows are 160 such tiles for 512 slots): narrower tiles until it does;
+//  (b) its last round would leave most slots idle: 2560 output rows x 4096 tokens are 640 tiles on 512 slots -- two rounds for
+//      1.25 rounds of work.  32-token tiles run THREE to a CU (132 registers, 32 KiB of LDS): 1280 tiles on 768 slots.  Measured,
+//      same box: o 74 -> 68 us, down 173 -> 160 us (quantiser included).  int8 form only: k_gemm_f16w's 32-token form (its staging
+//      and scale work per MFMA double) LOSES 2 % of the BitNet32-F16 prefill under the same rule.
+static int gemm_token_tiles(size_t gx0, size_t m_pad, bool tail_rule) {
+    int ttw = 4;
+    while (ttw > 1 && gx0 * (m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+    if (ttw == 4 && tail_rule) {
+        const size_t tiles = gx0 * (m_pad / 64), slots = 2 * kGemmCUs, rounds = div_ceil(tiles, slots);
+        if (4 * tiles < 3 * rounds * slots) ttw = 2;  // the last round under a quarter full on average: < 75 % of the slots used
+    }
+    return ttw;
+}
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -859,7 +875,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             // few activation rows (a short prompt, or one rank's share of a token-parallel prefill: 1024 rows x 2560 output rows
             // is 160 of these tiles for 512 slots): narrower token tiles until the grid covers the chip
             const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
-            while (ttw > 1 && gx0 * (q.m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+            ttw = gemm_token_tiles(gx0, q.m_pad, true);
             if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
             if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
         }
@@ -899,8 +915,7 @@ static hipError_t launch_gemm_f16w(const Weights &w, const QuantArgs &q, const G
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     // token tile: 64 (TTW 4) while the grid still covers the chip twice over, else narrower (short prompts, one rank's share)
     const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
-    int ttw = 4;
-    while (ttw > 1 && gx0 * (q.m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+    const int ttw = gemm_token_tiles(gx0, q.m_pad, false);
     void (*gk)(GemmArgs, uint32_t) = ttw == 4 ? k_gemm_f16w<4> : ttw == 2 ? k_gemm_f16w<2> : k_gemm_f16w<1>;
     const size_t lds = (size_t)ttw * 16 * kRowStrideH + 4 * 4096;
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 4};

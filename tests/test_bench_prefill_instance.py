@@ -64,6 +64,16 @@ def oracle_rows(oracle, lay, fmt, name, rows, cols, xs):
 
 
 EXPECT_TILE = {"qk256": dict(digits=2, wave_tokens=64, waves=4, scale_mode=0), "i2s": dict(digits=2, wave_tokens=64, waves=4, scale_mode=4)}
+# the 2560-row launches (o, down) at 4096 tokens: 640 64-token tiles would leave the second round a quarter full, so the launcher
+# takes 32-token tiles, three workgroups to a CU (kernels_gemm.hip gemm_token_tiles)
+NARROW_CASES = ("o_residual", "down_residual")
+
+
+def expect_tile(fmt, case):
+    t = dict(EXPECT_TILE[fmt])
+    if case in NARROW_CASES and fmt == "qk256":  # (the f16 form keeps 64: its 32-token tile measured slower)
+        t["wave_tokens"] = 32
+    return t
 
 
 @pytest.mark.parametrize("fmt", ["qk256", "i2s"])
@@ -105,7 +115,7 @@ def test_benchmarked_tile_matches_oracle(hip, oracle, torch_, layers, fmt, case)
     hip.matmul_fused_dev(h, xd, yd, M, ws, wsb, ln_gamma=gd, ln_eps=cfg.eps if gamma is not None else 0.0, residual=rd,
                          flags=1 if case == "gateup_ln_silu" else 0, digits=2)
     torch_.cuda.synchronize()
-    assert hip.matmul_last_tile() == EXPECT_TILE[fmt], hip.matmul_last_tile()  # the instance bench.py's c4 / c5 prefill runs
+    assert hip.matmul_last_tile() == expect_tile(fmt, case), hip.matmul_last_tile()  # the instance bench.py's c4 / c5 prefill runs
     got_all = yd.cpu().numpy()
     assert not np.isnan(got_all).any()
     got = got_all[sample]
@@ -222,7 +232,7 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
         dec.prefill(4096, with_logits=True, digits=digits)
         tile = hip.matmul_last_tile()
         out[digits] = (dec.last_logits().copy(), int(dec.history(4097)[4096]), dec.last_hidden().copy())
-    assert tile == EXPECT_TILE[fmt], tile
+    assert tile == expect_tile(fmt, "down_residual"), tile  # the prompt's last matmul is a down-projection
     assert cosine(out[2][0], out[4][0]) >= 0.9999
     assert cosine(out[2][2], out[4][2]) >= 0.9999
     assert out[2][1] == out[4][1]
