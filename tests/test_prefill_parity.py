@@ -80,6 +80,45 @@ SMALL = dict(hidden=512, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, ffn=
 WIDE = dict(hidden=2560, n_layers=2, n_heads=20, n_kv_heads=5, head_dim=128, ffn=6912, vocab=4096, max_pos=96, eps=1e-5, rope_theta=500000.0)
 
 
+@pytest.mark.parametrize("T,n_heads,n_kv", [(2560, 20, 5), (4096, 20, 5), (2200, 8, 8)])
+def test_prefill_attention_long_prompt_rows_match_f64_reference(hip, oracle, torch_, T, n_heads, n_kv):
+    """Long prompts (40 - 64 key tiles per query block): the first and last rows of query blocks, rows around the middle of the prompt
+    and its last row, against the f64 softmax of the same rows (T:410-533)."""
+    D, max_pos = 128, 4096
+    rng = np.random.default_rng(T + n_heads)
+    qkv = rng.normal(0, 1.2, (T, (n_heads + 2 * n_kv) * D)).astype(np.float32)
+    sin, cos = oracle.rope_tables(D, max_pos, 10000.0)
+    sin, cos = sin.reshape(max_pos, D // 2), cos.reshape(max_pos, D // 2)
+    rows = np.unique(np.concatenate([[0, 31, 32, 63, 64, 2047, 2048, 2079, 2080, 2111, 2112, 2143, T - 65, T - 64, T - 33, T - 32, T - 1],
+                                     rng.integers(0, T, 40)]))
+    rows = rows[(rows >= 0) & (rows < T)]
+    k = qkv[:, n_heads * D:(n_heads + n_kv) * D].reshape(T, n_kv, D).astype(np.float64)
+    v = qkv[:, (n_heads + n_kv) * D:].reshape(T, n_kv, D).astype(np.float64)
+    k = rope_np(k, sin[:T, None, :], cos[:T, None, :])
+    q = rope_np(qkv[rows, : n_heads * D].reshape(len(rows), n_heads, D).astype(np.float64), sin[rows, None, :], cos[rows, None, :])
+    group = n_heads // n_kv
+    want = np.zeros((len(rows), n_heads, D))
+    for i, r in enumerate(rows):
+        for h in range(n_heads):
+            sc = k[: r + 1, h // group] @ q[i, h] / np.sqrt(D)
+            pm = np.exp(sc - sc.max())
+            want[i, h] = (pm / pm.sum()) @ v[: r + 1, h // group]
+    dev = lambda a: torch_.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    kc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    vc = torch_.zeros(n_kv * max_pos * D, device="cuda")
+    wsb = hip.attention_prefill_workspace_bytes(n_heads, n_kv, T)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    out = torch_.full((T, n_heads * D), float("nan"), device="cuda")
+    for rep in range(2):  # twice on one workspace
+        hip.attention_prefill_dev(dev(qkv), dev(sin), dev(cos), kc, vc, n_heads, n_kv, D, max_pos, T, ws, wsb, out)
+        got_all = out.cpu().numpy()
+        assert np.isfinite(got_all).all()
+        got = got_all[rows].reshape(len(rows), n_heads, D)
+        # q, k, v and the probabilities pass through the matrix cores as f16 (2^-11 relative each)
+        assert np.max(np.abs(got - want)) <= 6e-3, np.max(np.abs(got - want))
+        assert cosine(got, want) >= 0.99999
+
+
 @pytest.mark.parametrize("cfgd,n_prompt,n_new,fmt", [(SMALL, 70, 6, "qk256"), (SMALL, 21, 4, "i2s"), (WIDE, 33, 4, "qk256")])
 def test_prefill_then_decode_matches_oracle(pkg, oracle, synth, cfgd, n_prompt, n_new, fmt):
     cfg = synth.ModelConfig(**cfgd)
