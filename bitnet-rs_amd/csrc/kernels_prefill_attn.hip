@@ -5,18 +5,22 @@
 // to the cache (T:1171-1202).  Here, for a FRESH sequence (positions 0..T-1):
 //
 //   k_prefill_prep  grid (T/64, heads + 2*kv_heads): one 64-token x 128-dim slab of q, k or v
-//                   through LDS: RoPE (q, k); q -> f16 [head][T][128]; k -> f16 [kv][T][128]
-//                   and the f32 decode cache (transposed, [kv][128][max_pos]); v -> f16
-//                   transposed [kv][128][T] and the f32 decode cache [kv][max_pos][128].
+//                   through LDS: RoPE (q, k); q -> f16 [head][T][128], pre-multiplied by the softmax
+//                   scale and log2(e); k -> f16 [kv][T][128] and the decode cache (f32 transposed
+//                   [kv][128][max_pos], or the f16 cache layout); v -> f16 transposed [kv][128][T]
+//                   with the keys of every 32-group in MFMA-operand order, and the decode cache.
 //                   Every global access is contiguous along the fastest index.
-//   k_prefill_attn  8 waves = (heads of one KV head) x (groups of 16 queries): flash attention on
-//                   v_mfma_f32_16x16x32_f16, f32 accumulation and f32 online softmax.
+//   k_prefill_attn  4 waves = (heads of one KV head) x (wave columns of 32 queries), two workgroups per
+//                   CU: flash attention on v_mfma_f32_16x16x32_f16, f32 accumulation, f32 online
+//                   softmax in base 2.  K / V^T tiles arrive by LDS-DMA into unpadded XOR-swizzled
+//                   double buffers; operand reads run two chunks ahead through a register ring.
 //                   It works on S^T = K Q^T and O^T = V^T P^T so that the probabilities never
 //                   leave registers: an S^T accumulator (lane: query c, keys 4g..4g+3) is
 //                   already in B-operand form for the second product once the V^T operand
 //                   uses the same key -> k-slot map.
+//   k_prefill_merge combines the key-split partials of launches too small to fill the chip.
 // q, k, v and the probabilities are rounded to f16 for the matrix cores (relative 2^-11);
-// the KV cache the decode steps read afterwards is the exact f32 values.
+// the f32 KV cache the decode steps read afterwards holds the exact f32 values.
 #include <cstdlib>
 #include <mutex>
 #include <unordered_set>
