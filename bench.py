@@ -601,7 +601,8 @@ def main():
             out["prefill"] = {"tokens": PROMPT_LEN, "ms": round(prefill_ms, 2), "tokens_per_s": round(PROMPT_LEN / prefill_ms * 1e3, 1),
                               "digits": args.digits, "eff_TFLOPs": round(flops / prefill_ms / 1e9, 1),
                               "note": "whole-prompt forward incl. first sampled token; I2_S projections on i8 MFMA digit planes, attention on f16 MFMA",
-                              "tile": prefill_tile, "prefill_check": prefill_chk, "roofline": prefill_roof}
+                              "last_matmul_tile": prefill_tile,  # the prompt's last matmul (a 2560-row down-projection: 32-token tiles at 4096 rows); roofline.tile = gate|up's
+                              "prefill_check": prefill_chk, "roofline": prefill_roof}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
     # N > 1: the decode line above is N independent replicas (batch-1 decode does not shard); the path's ONE real collective
