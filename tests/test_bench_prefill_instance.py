@@ -193,6 +193,41 @@ def _models(synth, fmt, cfg):
 
 
 @pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+@pytest.mark.parametrize("name", ["q", "down"])
+def test_full_size_matmul_properties_are_bit_exact(hip, torch_, layers, fmt, name):
+    """Size-independent properties of the benchmarked launches at m = 4096 (q: 64-token tiles; down: the narrow-tile rule), checked
+    on EVERY output, bit for bit:
+      * scaling the activations by a power of two scales the outputs by it (row scales are powers of two, digits / f16 mantissas
+        do not change) -- any rounding that depended on the tile position or the launch shape would break it;
+      * permuting the token rows permutes the output rows (a row's result does not depend on which tile, wave or round it is in);
+      * the first 1000 rows alone (another grid, narrower tiles) give the same rows."""
+    cfg, both = layers
+    lay = both[fmt]
+    rows, cols = cfg.shapes()[name]
+    h = upload(hip, lay, fmt, name, rows, cols)
+    rng = np.random.default_rng(zlib.crc32(f"prop/{fmt}/{name}".encode()))
+    x = (rng.normal(0, 1, (M, cols)) * np.exp(rng.uniform(-3, 3, (M, 1)))).astype(np.float32)
+    wsb = hip.matmul_workspace_bytes(M, cols, 2)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+
+    def run(xa, m=M):
+        xd = torch_.from_numpy(np.ascontiguousarray(xa)).cuda()
+        yd = torch_.full((m, rows), float("nan"), device="cuda")
+        hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, digits=2)
+        torch_.cuda.synchronize()
+        return yd.cpu().numpy()
+
+    y = run(x)
+    assert np.isfinite(y).all()
+    assert np.array_equal(run(x * np.float32(4.0)), y * np.float32(4.0))
+    assert np.array_equal(run(x * np.float32(0.125)), y * np.float32(0.125))
+    perm = rng.permutation(M)
+    assert np.array_equal(run(x[perm]), y[perm])
+    assert np.array_equal(run(x[:1000], 1000), y[:1000])
+    hip.weights_free(h)
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
 def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle, synth, fmt):
     cfg = synth.ModelConfig(**WIDE)
     glob, layers, olayers = _models(synth, fmt, cfg)
