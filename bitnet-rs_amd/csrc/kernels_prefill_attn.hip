@@ -216,6 +216,19 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+// max over the four lanes (c, g = 0..3) that hold one query's keys, in every lane, on the VALU: v_permlane16_swap / v_permlane32_swap
+// (gfx950) instead of two dependent ds_bpermute round trips through the LDS pipe per query group and key tile.  With both operands
+// the same register, permlane16_swap leaves (rows 0, 0, 2, 2) and (rows 1, 1, 3, 3) of 16 lanes, permlane32_swap (low half twice)
+// and (high half twice): the maximum of each pair is the xor-16 / xor-32 butterfly step.
+__device__ __forceinline__ float max_over_g(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m1 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(m1);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // LDS-DMA: 64 lanes x 16 B from (scalar base + per-lane byte offset) to LDS bytes [lds_dst, lds_dst + 1024).  Invisible to hipcc's
 // vmcnt bookkeeping (cdna_hip_programming.md 5.7): the kernel waits with explicit s_waitcnt vmcnt(0) and issues no other vector
 // memory loads while these are in flight.
@@ -407,8 +420,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mt = max3_raw(max3_raw(mt, s[q][i][0], s[q][i][1]), s[q][i][2], s[q][i][3]);
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 16));
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            mt = max_over_g(mt);
             // mt is relative to the running reference.  The reference only moves when the maximum outgrows it by more than 2^8 (the
             // f16 probabilities then stay <= 256, the sums are f32): most tiles skip both the shift of the scores and the rescaling
             // of the 32 output accumulators.  A tile wholly above a query's limit (a later key split's first tile: its 64-row block
