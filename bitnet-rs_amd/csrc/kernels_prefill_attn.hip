@@ -403,10 +403,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         // Only tiles that reach past some query's limit are masked (the diagonal ones, and the context's last): wave-uniform.
         const bool need_mask = kt * kQB + kQB - 1 > qmin;
         v8h pb[NQ][2];
+        // The query groups' softmax chains are independent: each stage below handles ALL groups in one basic block (one branch per
+        // stage, not per group), so hipcc interleaves their dependent chains -- maximum, exponentials, sum -- instead of running
+        // them one after the other.
+        float mt[NQ];
+        if (need_mask) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float mt = -INFINITY;
-            if (need_mask) {
+            for (int q = 0; q < NQ; ++q) {
+                mt[q] = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -414,23 +418,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
                         const int pos = kt * kQB + 16 * i + 4 * g + j;
                         const float v = pos <= qlim[q] ? s[q][i][j] : -INFINITY;  // causal mask (T:452-470) / end of the context
                         s[q][i][j] = v;
-                        mt = fmaxf(mt, v);
+                        mt[q] = fmaxf(mt[q], v);
                     }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mt = max3_raw(max3_raw(mt, s[q][i][0], s[q][i][1]), s[q][i][2], s[q][i][3]);
             }
-            mt = max_over_g(mt);
-            // mt is relative to the running reference.  The reference only moves when the maximum outgrows it by more than 2^8 (the
-            // f16 probabilities then stay <= 256, the sums are f32): most tiles skip both the shift of the scores and the rescaling
-            // of the 32 output accumulators.  A tile wholly above a query's limit (a later key split's first tile: its 64-row block
-            // spans several query groups) leaves mt = -inf: the clamp keeps 2^(-inf - -inf) out and the reference stays "unset".
-            const bool unset = m_run[q] < -1.0e30f;
-            const bool grow = mt > 8.0f || unset;
-            if (__any(grow)) {
-                const float shift = grow ? fmaxf(mt, -3.0e38f) : 0.0f;
-                const float m_new = unset ? shift : m_run[q] + shift;
-                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {  // two half-chains per group
+                const float ma = max3_raw(max3_raw(max3_raw(s[q][0][0], s[q][0][1], s[q][0][2]), s[q][0][3], s[q][1][0]), s[q][1][1], s[q][1][2]);
+                const float mb = max3_raw(max3_raw(max3_raw(s[q][2][0], s[q][2][1], s[q][2][2]), s[q][2][3], s[q][3][0]), s[q][3][1], s[q][3][2]);
+                mt[q] = max3_raw(max3_raw(ma, mb, s[q][1][3]), s[q][3][3], -INFINITY);
+            }
+        }
+        // mt is relative to the running reference.  The reference only moves when the maximum outgrows it by more than 2^8 (the
+        // f16 probabilities then stay <= 256, the sums are f32): most tiles skip both the shift of the scores and the rescaling
+        // of the 32 output accumulators.  A tile wholly above a query's limit (a later key split's first tile: its 64-row block
+        // spans several query groups) leaves mt = -inf: the clamp keeps 2^(-inf - -inf) out and the reference stays "unset".
+        bool unset[NQ], grow[NQ], any_grow = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            mt[q] = max_over_g(mt[q]);
+            unset[q] = m_run[q] < -1.0e30f;
+            grow[q] = mt[q] > 8.0f || unset[q];
+            any_grow = any_grow || grow[q];
+        }
+        if (__any(any_grow)) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float shift = grow[q] ? fmaxf(mt[q], -3.0e38f) : 0.0f;
+                const float m_new = unset[q] ? shift : m_run[q] + shift;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);  // (no lane of the group grows: shift 0, alpha 1)
                 l_run[q] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) o[q][dt] *= alpha;
@@ -440,16 +456,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s[q][i][j] -= shift;
             }
-            float lsum = 0.0f;
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < NQ; ++q) {
+            float ls[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(s[q][i][j]);
-                    s[q][i][j] = e;
-                    lsum += e;
-                }
-            l_run[q] += lsum;
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[q][i][j] = __builtin_amdgcn_exp2f(s[q][i][j]);
+                ls[i] = (s[q][i][0] + s[q][i][1]) + (s[q][i][2] + s[q][i][3]);
+            }
+            l_run[q] += (ls[0] + ls[1]) + (ls[2] + ls[3]);
             // P^T operand: k-slot (g, j) = key 32u + 4g + j (j < 4), 32u + 16 + 4g + (j - 4)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
