@@ -36,6 +36,26 @@ COMMON_FLAGS = [
 EXTRA = {"kernels_exact.hip": ["-ffp-contract=off"]}
 
 
+# The hand-counted `s_waitcnt vmcnt(N)` around the LDS-DMA of k_prefill_attn (and the register / scratch figures DESIGN.md
+# quotes) were validated on this toolchain: tests/test_isa_guard.py re-checks them from the emitted ISA.
+VALIDATED_HIPCC = "HIP version: 7.2.26015-fc0010cf6a"
+
+
+def hipcc_version() -> str:
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return ""
+    return out.splitlines()[0].strip() if out else ""
+
+
+def warn_if_unvalidated_hipcc() -> None:
+    v = hipcc_version()
+    if v != VALIDATED_HIPCC:
+        sys.stderr.write(f"warning: hipcc is '{v}', the hand-counted vmcnt waits of kernels_prefill_attn.hip were validated on "
+                         f"'{VALIDATED_HIPCC}': run `pytest tests/test_isa_guard.py` before trusting this build\n")
+
+
 def sources() -> list[str]:
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -76,6 +96,8 @@ def _build(force: bool, verbose: bool, OBJ_DIR: str, LIB_PATH: str, extra_all: l
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    if procs:
+        warn_if_unvalidated_hipcc()
     failed = False
     for src, p in procs:
         out, _ = p.communicate()

@@ -328,9 +328,13 @@ static int upload_coded(const uint8_t *weights_packed, size_t w_len, const float
     w->lut = lut;
     w->scaled = true;
     if (block_size == 32) {  // f16-exact scales (BitNet32-F16): keep them as f16 in the streaming layout
-        bool exact = true;
-        for (size_t i = 0; i < n * nblk && exact; ++i) exact = (float)(_Float16)scales[i] == scales[i];
+        bool exact = true, x2 = true;
+        for (size_t i = 0; i < n * nblk && exact; ++i) {
+            exact = (float)(_Float16)scales[i] == scales[i];
+            x2 = x2 && fabsf(scales[i]) <= 32752.0f;
+        }
         w->scales_f16 = exact;
+        w->scales_f16_x2_finite = exact && x2;
     }
     w->algorithmic_bytes = packed_k * n + (w->scales_f16 ? 2 : 4) * n * nblk;
     w->device = g_device;
@@ -447,7 +451,7 @@ static int matmul_dev_kernel(bitnet_hip_weights_t h, const float *x_dev, float *
         const size_t wsb = gemm_workspace_bytes(m, w->cols, 4);
         std::unique_ptr<ReferencePin> pin;  // row-major block scales: held until the launch is enqueued
         if (gemm_needs_row_major_scales(*w)) {
-            pin.reset(new ReferencePin(*w, (hipStream_t)stream));
+            pin.reset(new ReferencePin(*w, (hipStream_t)stream, /*scales_only=*/true));
             if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
         }
         void *ws = nullptr;
@@ -499,7 +503,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_dev ? workspace_bytes : (size_t)0);
     std::unique_ptr<ReferencePin> pin;  // row-major block scales: held until the launch is enqueued
     if (gemm_needs_row_major_scales(*w)) {
-        pin.reset(new ReferencePin(*w, (hipStream_t)stream));
+        pin.reset(new ReferencePin(*w, (hipStream_t)stream, /*scales_only=*/true));
         if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
     }
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
@@ -585,6 +589,7 @@ int bitnet_hip_weights_concat(const bitnet_hip_weights_t *parts, size_t n_parts,
     f->ln_g = nullptr;
     f->ln_gamma_bound = nullptr;
     for (const WeightsRef &w : ws) f->scales_f16 = f->scales_f16 && w->scales_f16;
+    for (const WeightsRef &w : ws) f->scales_f16_x2_finite = f->scales_f16_x2_finite && w->scales_f16_x2_finite;
     f->rows = rows;
     f->paired = interleave16 != 0;
     f->algorithmic_bytes = 0;

@@ -76,6 +76,8 @@ struct Weights {
     // Every scale is exactly an f16 value (BitNet32-F16 files store them so): the streaming layout
     // keeps them as f16 (2 bytes per 32 weights instead of 4) -- same numbers, fewer bytes.
     bool scales_f16 = false;
+    // ... and +-2 s stays finite in f16 (|s| <= 32752): the prefill's k_gemm_f16w multiplies the code value into the scale in f16
+    bool scales_f16_x2_finite = false;
     uint16_t *scale_tiles_h = nullptr;
     size_t n_row_tiles = 0, n_kblocks = 0;
     bool paired = false;  // rows are interleaved (gate tile, up tile) pairs (weights_concat interleave16)
@@ -141,7 +143,10 @@ hipError_t launch_embed_q(const void *table, const int *tokens, const int *offse
 hipError_t build_tiles(Weights &w, hipStream_t stream);
 // codes / scales in the reference layout, rebuilt from the tiles if they were dropped (exact inverse permutation);
 // synchronises `stream` when it had to rebuild.  trim_reference drops them again when the tiles can stand in.
-hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin = false);
+// scales_only: the caller reads `scales` alone (the prefill matmul's row-major block scales): the trimmed row-major CODES are
+// not re-materialised -- one copy of the codes stays on the device, and when `scales` exists already nothing is allocated,
+// launched or synchronised (safe under stream capture).
+hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin = false, bool scales_only = false);
 void trim_reference(Weights &w);
 // Holds the reference-layout copies from "rebuilt if missing" until the launch that reads them has been ENQUEUED: another thread's
 // trim_reference (bitnet_hip_weights_trim, weights_concat) skips a pinned matrix; once the pin is gone a trim's hipFree waits for
@@ -149,7 +154,7 @@ void trim_reference(Weights &w);
 struct ReferencePin {
     Weights &w;
     hipError_t status;
-    ReferencePin(Weights &w_, hipStream_t stream) : w(w_), status(ensure_reference(w_, stream, true)) {}
+    ReferencePin(Weights &w_, hipStream_t stream, bool scales_only = false) : w(w_), status(ensure_reference(w_, stream, true, scales_only)) {}
     ~ReferencePin() {
         if (status == hipSuccess) w.ref_pins->fetch_sub(1, std::memory_order_acq_rel);
     }

@@ -898,6 +898,16 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     return hipGetLastError();
 }
 
+// k_gemm_f16w builds (code value) x (block scale) in f16: only code maps whose four values are in -2 .. 2 (every map of the
+// reference: their f16 images have a zero low byte, lut_f16_hi) and scales whose double is finite in f16 take it; any other
+// matrix (bitnet_hip_weights_upload_coded accepts an arbitrary int8 code map) keeps the exact int8 digit form.
+static bool lut_fits_f16w(uint32_t lut) {
+    for (int c = 0; c < 4; ++c) {
+        const int v = (int)(int8_t)((lut >> (8 * c)) & 0xffu);
+        if (v < -2 || v > 2) return false;
+    }
+    return true;
+}
 // code map values -> the high bytes of their f16 images (every value of the reference's maps, -2 .. 2, has a zero low byte)
 static uint32_t lut_f16_hi(uint32_t lut) {
     uint32_t out = 0;
@@ -957,7 +967,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
-    if (ndig == 2 && k32) return launch_gemm_f16w(w, q, a, stream);  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
+    if (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite) return launch_gemm_f16w(w, q, a, stream);  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
     return launch_gemm_t<4, 2>(w, q, a, stream);

@@ -855,7 +855,7 @@ void trim_reference(Weights &w) {
     }
 }
 
-hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin) {
+hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin, bool scales_only) {
     std::lock_guard<std::mutex> lk(*w.mu);
     struct PinOnSuccess {  // the pin is taken under the lock, on every successful return
         Weights &w;
@@ -869,7 +869,7 @@ hipError_t ensure_reference(Weights &w, hipStream_t stream, bool pin) {
     PinOnSuccess guard{w, pin, &result};
     const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256);
     bool built = false;
-    if (!w.codes) {
+    if (!w.codes && !scales_only) {
         if (!w.tiles) return result = hipErrorInvalidValue;
         const size_t bytes = w.rows * w.row_stride_bytes + 16;
         hipError_t e = hipMalloc((void **)&w.codes, bytes);

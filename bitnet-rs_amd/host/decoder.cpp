@@ -854,13 +854,20 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
     }
     hipStream_t s = (hipStream_t)stream_;
     if (world > 1 && !comm_stream_) {  // the collective's own stream + the two events that tie it to the compute stream
-        hipStream_t cs;
-        hipEvent_t e1, e2;
-        HCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        // all three or none: a later call must never find the stream set and an event missing
+        hipStream_t cs = nullptr;
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        hipError_t er = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (er == hipSuccess) er = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+        if (er == hipSuccess) er = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+        if (er != hipSuccess) {
+            if (e2) (void)hipEventDestroy(e2);
+            if (e1) (void)hipEventDestroy(e1);
+            if (cs) (void)hipStreamDestroy(cs);
+            HCHK(er);
+        }
         comm_stream_ = cs;
-        HCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
         sp_ev_pack_ = e1;
-        HCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
         sp_ev_gather_ = e2;
     }
     {

@@ -177,3 +177,47 @@ def test_full_size_gemm_properties(hip, torch_):
     bound = np.abs(x).max(axis=1, keepdims=True) * 2.0 ** -21 * 2 * k     # <= 2^-22 of the row maximum per element, |w| <= 2
     assert np.all(np.abs(y3 - y4) <= bound + 1e-6)
     hip.weights_free(h)
+
+
+def test_digits2_with_a_code_map_outside_the_f16_weight_form(hip, torch_):
+    """bitnet_hip_weights_upload_coded takes ANY int8 code map; k_gemm_f16w (digits = 2 on f16-exact 32-block scales)
+    can only build code values -2 .. 2 (and needs 2 |s| finite in f16).  Any other matrix must keep the exact int8 digit form
+    instead of producing NaN / inf: {-3, -1, 1, 3}, and a map the f16 form does take but with scales beyond its range."""
+    rng = np.random.default_rng(5)
+    n, k, m, block = 256, 512, 40, 32
+    codes = rng.integers(0, 4, (n, k), dtype=np.uint8)
+    packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
+    x = rng.uniform(-4, 4, (m, k)).astype(np.float32)
+    for cmap, smax, f16w in (((-3, -1, 1, 3), 1.0, False), ((-2, -1, 1, 2), 40000.0, False), ((-2, -1, 1, 2), 1.0, True)):
+        scales = (smax / ((np.arange(n * (k // block)) % 7) + 1)).astype(np.float16).astype(np.float32)
+        wfull = np.asarray(cmap, np.float64)[codes] * np.repeat(scales.reshape(n, k // block), block, axis=1)
+        want = x.astype(np.float64) @ wfull.T
+        h = hip.weights_upload_coded(packed.reshape(-1), scales, n, k, block, cmap)
+        got = run_gemm(hip, torch_, h, x, n, 2)
+        assert np.isfinite(got).all(), cmap
+        assert (hip.matmul_last_tile()["scale_mode"] == 4) == f16w, (cmap, smax, hip.matmul_last_tile())
+        assert np.max(np.abs(got - want)) <= 1e-3 * np.max(np.abs(want)), (cmap, smax)
+        for i in range(m):
+            assert cosine(got[i], want[i]) >= 0.99999
+        hip.weights_free(h)
+
+
+def test_matmul_on_block256_scales_keeps_one_copy_of_the_codes(hip, torch_):
+    """a matrix with 256-element block scales reads its row-major scales in the prefill matmul; taking the pin must not
+    re-materialise the trimmed row-major CODES (a second copy of the weights, a hipMalloc and a host synchronisation in the call)."""
+    rng = np.random.default_rng(6)
+    n, k, m, block = 512, 1024, 64, 256
+    codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(n, k))
+    packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
+    scales = rng.uniform(0.5, 1.5, n * (k // block)).astype(np.float32)
+    h = hip.weights_upload_i2s(packed.reshape(-1), scales, n, k, block)
+    x = rng.normal(0, 1, (m, k)).astype(np.float32)
+    run_gemm(hip, torch_, h, x, n, 4)  # (first use may build the streaming layout)
+    hip.weights_trim(h)
+    before = hip.weights_device_bytes(h)
+    for digits in (2, 3, 4):
+        run_gemm(hip, torch_, h, x, n, digits)
+        assert hip.weights_device_bytes(h) == before, digits
+    code_bytes = -(-n // 16) * (k // 256) * 1024
+    assert before < 2 * code_bytes
+    hip.weights_free(h)

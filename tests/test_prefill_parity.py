@@ -376,6 +376,90 @@ def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T
         dd.prefill_sharded(100, 0, 2, lambda *a: 0)
 
 
+@pytest.mark.parametrize("world,T,wire_f16", [(2, 512, True), (4, 1024, False)])
+def test_cpp_sharded_prefill_asynchronous_gather_no_host_sync(pkg, hip, synth, torch_, world, T, wire_f16):
+    """The all-gather as a collective library issues it: the callback only ENQUEUES work on the stream it is handed (the
+    decoder's comm stream) -- device-to-device copies out of every rank's send buffer, ordered by events between the ranks'
+    streams -- and returns without a host-device synchronisation.  What orders the pack before the gather, the gather before
+    the k / v phase of the attention, and the next layer's pack behind the readers of the send buffer is then ONLY the
+    decoder's own event pair (sp_ev_pack_ / sp_ev_gather_) plus the callback's events: the path RCCL takes.
+    The host-side barriers only make sure an event has been RECORDED (a host call) before another thread waits on it."""
+    import ctypes as C
+    import threading
+
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    rt.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    rt.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rt.hipEventDestroy.argtypes = [C.c_void_p]
+    D2D, NO_TIMING = 3, 2
+    cfg = synth.ModelConfig(**dict(SMALL, max_pos=T + 64))
+    layers = [synth.make_layer(cfg, l) for l in range(cfg.n_layers)]
+    glob = synth.make_globals(cfg)
+    prompt = synth.prompt(T, cfg.vocab)
+
+    def make():
+        d = pkg.HostDecoder(cfg)
+        for l, w in enumerate(layers):
+            d.set_layer_qk256(l, w)
+        d.set_globals(glob)
+        d.reset()
+        d.feed(prompt)
+        return d
+
+    ref = make()
+    ref.prefill(T, with_logits=True, digits=3)
+    want_logits = ref.last_logits()
+    ref.close()
+    decs = [make() for _ in range(world)]
+
+    def event():
+        e = C.c_void_p()
+        assert rt.hipEventCreateWithFlags(C.byref(e), NO_TIMING) == 0
+        return e
+
+    ready = [event() for _ in range(world)]  # rank's send buffer is packed (its comm stream already waits for the pack event)
+    done = [event() for _ in range(world)]   # rank has copied out of everybody's send buffer
+    sends, bar, errors, host_syncs = [None] * world, threading.Barrier(world), [], []
+
+    def gather_for(rank):
+        def gather(send, recv, nbytes, stream):
+            sends[rank] = send
+            assert rt.hipEventRecord(ready[rank], stream) == 0
+            bar.wait(timeout=60)  # every ready[] has been recorded for this layer
+            for q in range(world):
+                assert rt.hipStreamWaitEvent(stream, ready[q], 0) == 0
+                assert rt.hipMemcpyAsync(C.c_void_p(recv + q * nbytes), C.c_void_p(sends[q]), nbytes, D2D, stream) == 0
+            assert rt.hipEventRecord(done[rank], stream) == 0
+            bar.wait(timeout=60)  # every done[] has been recorded
+            for q in range(world):  # like a collective: complete on this rank once nobody reads its send buffer any more
+                assert rt.hipStreamWaitEvent(stream, done[q], 0) == 0
+            return 0
+        return gather
+
+    def run(rank):
+        try:
+            decs[rank].prefill_sharded(T, rank, world, gather_for(rank), with_logits=True, digits=3, wire_f16=wire_f16)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    got = decs[0].last_logits()
+    assert cosine(got, want_logits) >= 0.999999 and np.max(np.abs(got - want_logits)) <= 1e-3 * np.max(np.abs(want_logits))
+    for d in decs:
+        assert d.position() == T
+        d.close()
+    for e in ready + done:
+        rt.hipEventDestroy(e)
+
+
 @pytest.mark.parametrize("wire_f16", [False, True])
 def test_gathered_attention_world8_8k_matches_unsharded_and_f64(hip, oracle, torch_, wire_f16):
     """bitnet_hip_attention_prefill_gathered_dev exactly as the 8-GPU run of BASELINE configs[4] calls it: 8192 positions in 16
