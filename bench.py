@@ -53,18 +53,22 @@ def build_model_from_gguf(pkg, synth, path: str, max_pos: int):
     return cfg, dec, None
 
 
-def build_model(pkg, synth, workload: str, layers_override: int | None, gguf: str | None = None):
+_GLOBALS = {}  # the synthetic embedding table / norms (13 s of host time to draw): one per (vocab, hidden), shared by every model of a run
+
+
+def build_model(pkg, synth, workload: str, layers_override: int | None, gguf: str | None = None, fmt: str | None = None, max_pos: int | None = None):
     if gguf:
         return build_model_from_gguf(pkg, synth, gguf, 4736 if workload == "c4" else 8256 if workload == "c5" else 1024)
     cfg = synth.ModelConfig(**synth.BITNET_2B_4T)
     if layers_override:
         cfg.n_layers = layers_override
     # KV cache sized for the workload: 128-token prompt + decode steps, or 4k prompt + 512 decode (c4)
-    cfg.max_pos = 4736 if workload == "c4" else 8256 if workload == "c5" else 1024
+    cfg.max_pos = max_pos or (4736 if workload == "c4" else 8256 if workload == "c5" else 1024)
+    fmt = fmt or ("qk256" if workload in ("c3", "c4", "c5") else "i2s")
     dec = pkg.HostDecoder(cfg)
     keep = None
     for l in range(cfg.n_layers):
-        if workload in ("c3", "c4", "c5"):
+        if fmt == "qk256":
             w = synth.make_layer(cfg, l, fmt="qk256")
             dec.set_layer_qk256(l, w)
         else:
@@ -72,7 +76,10 @@ def build_model(pkg, synth, workload: str, layers_override: int | None, gguf: st
             dec.set_layer_i2s(l, w, 32)
         if l == 0:
             keep = w
-    dec.set_globals(synth.make_globals(cfg))
+    key = (cfg.vocab, cfg.hidden)
+    if key not in _GLOBALS:
+        _GLOBALS[key] = synth.make_globals(cfg)
+    dec.set_globals(_GLOBALS[key])
     return cfg, dec, keep
 
 
@@ -89,6 +96,27 @@ def load_traffic(workload: str):
         return int(t["hbm_fetch_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch"])
     except (OSError, KeyError, ValueError, TypeError):
         return None
+
+
+def load_rocprof_us(workload: str):
+    """rocprofv3's average duration of the dominant kernel from the committed summary of the same command (profiles/traffic_<workload>.json,
+    key avg_us_rocprof; tools/profile_round.sh), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"traffic_{workload}.json")) as f:
+            return float(json.load(f)["avg_us_rocprof"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, synth):
@@ -151,6 +179,8 @@ def cpu_baseline(cfg, synth):
         "value": round(tok_s, 4),
         "unit": "tokens/s",
         "cores": 1,
+        "cpu_model": cpu_model(),
+        "host_threads_available": n_cores,
         "kind": "port",
         **extra,
         "sample": f"oracle/ restatement of gemv_qk256_{impl} on 1 layer (7 GEMVs, 17.4 MB codes), median of 5 after 1 warm-up = "
@@ -225,26 +255,43 @@ def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int =
             launch()
         stream.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = None
-    for _ in range(3 if launches is None else 0):
-        e0.record(stream)
-        for _ in range(reps):
+    bursts, singles = [], []
+    if launches is None:
+        for _ in range(5):  # throughput reading: `reps` launches back to back -- one launch's drain overlaps the next one's fill
+            e0.record(stream)
+            for _ in range(reps):
+                launch()
+            e1.record(stream)
+            stream.synchronize()
+            bursts.append(e0.elapsed_time(e1) * 1e3 / reps)
+        for _ in range(2 * reps + 1):  # per-kernel reading: every launch alone between its own pair of events (what rocprofv3's duration shows)
+            e0.record(stream)
             launch()
-        e1.record(stream)
-        stream.synchronize()
-        us_launch = e0.elapsed_time(e1) * 1e3 / reps
-        best = us_launch if best is None or us_launch < best else best
+            e1.record(stream)
+            stream.synchronize()
+            singles.append(e0.elapsed_time(e1) * 1e3)
     _, _, wbytes = hip.weights_info(h)
     # algorithmic bytes of one launch: codes + scales, QAct records + statistics pairs in, g_r per stored row, QAct out
     abytes = wbytes + hip.qact_bytes(K) + hip.qact_stats_bytes(K) + 8 * F + hip.qact_bytes(F)
     hip.weights_free(h)
     out = {"kernel": "k_gemv_q (the decode step's fused LayerNorm -> gate|up GEMV -> silu*mul instance, one launch over the whole matrix)",
            "format": "BitNet32-F16" if fmt == "i2s" else "QK256", "rows": 2 * F, "cols": K, "bytes_per_launch": int(abytes)}
-    if best is not None:
-        gbs = abytes / best / 1e3
-        out.update({"us_per_launch": round(best, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "launches_timed": reps, "timing": "HIP events on the launch stream, best of 3 bursts",
+    if singles:
+        us_k, us_b, us_best = float(np.median(singles)), float(np.median(bursts)), float(min(bursts))
+        gbs = abytes / us_k / 1e3
+        out.update({"us_per_launch": round(us_k, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "timing": f"HIP events on the launch stream around ONE launch at a time, median of {len(singles)} (the per-kernel duration; "
+                              "compare us_per_kernel_rocprof)",
+                    "burst": {"launches": reps, "bursts": len(bursts), "us_per_launch_median": round(us_b, 2), "us_per_launch_best": round(us_best, 2),
+                              "frac_median": round(abytes / us_b / 1e3 / HBM_PEAK_GBS, 4), "frac_best": round(abytes / us_best / 1e3 / HBM_PEAK_GBS, 4),
+                              "note": "back-to-back launches: the first workgroups of launch n + 1 start on the CUs launch n's last round has left, so the "
+                                      "period between launches is shorter than one kernel's own start-to-end duration (fill / drain overlap); a throughput "
+                                      "figure, not a per-kernel one"},
                     "traffic": load_traffic("stream_" + fmt)})
+        rp = load_rocprof_us("stream_" + fmt)
+        if rp is not None:
+            out["us_per_kernel_rocprof"] = rp
+            out["frac_from_rocprof"] = round(abytes / rp / 1e3 / HBM_PEAK_GBS, 4)
     return out
 
 
@@ -314,6 +361,80 @@ def prefill_check(dec, prompt, n: int, digits: int, timed_state):
             "same_first_token": bool(token_t == token_4), "digits_timed": digits, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
+def also_workloads(args, pkg, synth, hip, use_graph: bool):
+    """configs[2], configs[3] and the BitNet32-F16 prefill in the SAME process as the headline line, after its measurement and outside
+    its timed region (the driver only times the default command, so c3 / c4 used to be builder-run claims).  Each
+    part has its own warm-up; `python bench.py --workload c3|c4` remain the full-length lines (profiles/r04_*_bench.json)."""
+    import torch
+
+    t_begin = time.perf_counter()
+    out = {}
+
+    def decode(dec, steps, warmup):
+        if use_graph:
+            dec.prepare_graphs(True)
+        dec.run(warmup, with_logits=True, use_graph=use_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_ms = dec.run(steps, with_logits=True, use_graph=use_graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        us, ab = dec.probe_gateup(50)
+        gbs = ab / us / 1e3
+        return {"value": round(steps / dt, 2), "unit": "tokens/s", "ms_per_step": round(dt / steps * 1e3, 4), "event_ms_per_step": round(ev_ms / steps, 4),
+                "steps": steps, "warmup": warmup,
+                "roofline": {"bound": "hbm", "kernel": "k_gemv_q (fused LayerNorm -> gate|up GEMV -> silu*mul)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": int(ab), "us_per_launch": round(us, 3)}}
+
+    # ---- configs[2]: QK256, batch-1 decode after a 128-token prompt (f32 KV cache, as `--workload c3`); the decoder's cache is sized for c4
+    cfg, dec, _ = build_model(pkg, synth, "c4", None)
+    prompt = synth.prompt(128, cfg.vocab)
+    dec.reset()
+    dec.feed(prompt)
+    dec.run(127, with_logits=False, use_graph=use_graph)
+    dec.run(1, with_logits=True, use_graph=use_graph)
+    c3 = decode(dec, 128, 16)
+    c3["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt", "kv_len_during_timing": [145, 273], "kv_cache": "f32"}
+    out["c3"] = c3
+    # ---- configs[3]: 4096-token prefill + decode at 4.1 - 4.2 k keys, f16 KV cache (the c4 default)
+    T = 4096
+    prompt = synth.prompt(T, cfg.vocab)
+    dec.reset()
+    dec.set_kv_f16(True)
+    dec.feed(prompt)
+    dec.prefill(T, with_logits=True, digits=args.digits)  # untimed warm-up pass
+    dec.reset()
+    dec.feed(prompt)
+    ms = dec.prefill(T, with_logits=True, digits=args.digits)
+    tile = hip.matmul_last_tile()
+    state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
+    c4 = decode(dec, 128, 8)
+    flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * T + 4.0 * T * T / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
+    c4["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, 4096-token prefill + decode", "kv_len_during_timing": [T + 1 + 8, T + 1 + 8 + 128],
+                    "kv_cache": "f16 (values rounded once, when appended)"}
+    c4["prefill"] = {"tokens": T, "ms": round(ms, 2), "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
+                     "last_matmul_tile": tile, "prefill_check": prefill_check(dec, prompt, T, args.digits, state),
+                     "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, True)}
+    out["c4"] = c4
+    dec.close()
+    # ---- the same prompt through the headline storage format (BitNet32-F16: k_gemm_f16w on the f16 matrix cores at 2 digits)
+    cfg, dec, _ = build_model(pkg, synth, "c2", None, max_pos=T + 128)
+    dec.reset()
+    dec.set_kv_f16(True)
+    dec.feed(prompt)
+    dec.prefill(T, with_logits=True, digits=args.digits)
+    dec.reset()
+    dec.feed(prompt)
+    ms = dec.prefill(T, with_logits=True, digits=args.digits)
+    state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
+    out["prefill_i2s"] = {"workload": "bitnet-b1.58-2B-4T I2_S BitNet32-F16, 1xMI355X, 4096-token prefill", "tokens": T, "ms": round(ms, 2),
+                          "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
+                          "prefill_check": prefill_check(dec, prompt, T, args.digits, state), "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, False)}
+    dec.close()
+    out["wall_s"] = round(time.perf_counter() - t_begin, 1)
+    return out
+
+
 def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps: int, warmup: int):
     """BASELINE configs[4]: ONE long prompt, token-parallel over the ranks (zigzag chunks, replicated weights, one all-gather
     of the k|v rows per layer; Decoder::prefill_sharded, bitnet-rs_amd/host/decoder.cpp).  The collective is RCCL over xGMI
@@ -366,6 +487,27 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
     # not timed: the same prompt through the 4-digit form (every rank takes part: the collective runs again); rank 0 holds the
     # last prompt position, hence the logits
     logits_t = dec.last_logits().astype(np.float64) if r.rank == 0 else None
+    # not timed either: one more pass at the timed digit count with per-phase events on (8 records per layer), so the first run on real
+    # ranks is diagnosable from its one line: medians over the layers on EVERY rank, the slowest rank's reported
+    dec.set_phase_timing(True)
+    one()
+    dec.set_phase_timing(False)
+    ph = dec.phase_times()
+    phases = dict(ph, rank=r.rank, per_layer_us=round(sum(v for k, v in ph.items() if k != "gather_us"), 1))
+    if r.world > 1:
+        import torch.distributed as dist
+
+        dev = "cuda" if r.backend == "nccl" else "cpu"
+        mine = torch.tensor([ph["matmul_us"], ph["attention_us"], ph["gather_wait_us"], ph["gather_us"]], device=dev)
+        allp = torch.empty(r.world * 4, device=dev)
+        dist.all_gather_into_tensor(allp, mine)
+        allp = allp.cpu().reshape(r.world, 4).numpy()
+        slow = int(np.argmax(allp[:, :3].sum(axis=1)))
+        phases = {"matmul_us": round(float(allp[slow, 0]), 1), "attention_us": round(float(allp[slow, 1]), 1), "gather_wait_us": round(float(allp[slow, 2]), 1),
+                  "gather_us": round(float(allp[slow, 3]), 1), "rank": slow, "per_layer_us": round(float(allp[slow, :3].sum()), 1),
+                  "per_layer_us_by_rank": [round(float(x), 1) for x in allp[:, :3].sum(axis=1)]}
+    phases["note"] = ("medians over the layers, slowest rank: matmul = q|k|v + pack + o + gate|up + down, attention = query-side phase + k/v phase, "
+                      "gather_wait = what the compute stream waited for the collective beyond the query-side phase, gather = the collective on its own stream")
     one(4)
     check = None
     if r.rank == 0:
@@ -382,7 +524,7 @@ def sharded_prefill(args, pkg, synth, dist_, r, cfg, dec, prompt_len: int, steps
         "workload": f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {r.world}xMI355X token-parallel prefill, {prompt_len}-token prompt",
         "tokens": prompt_len, "steps": steps, "ms_per_prompt": round(elapsed / steps * 1e3, 3), "tokens_per_s": round(prompt_len * steps / elapsed, 1),
         "eff_TFLOPs": round(flops * steps / elapsed / 1e12, 1), "digits": args.digits, "ranks_seen": seen, "first_sampled_token": token,
-        "prefill_check": check,
+        "prefill_check": check, "phases": phases,
         "parallelism": f"token-parallel x{r.world} (zigzag chunks), weights replicated",
         "collective": f"all-gather of k|v rows (f16 on the wire) per layer: {kv_bytes} B x {cfg.n_layers} layers; {how}" if r.world > 1 else how,
         "scaling": "strong",
@@ -424,6 +566,7 @@ def main():
                     "same sampled token -- tools/perf_prefill_digits.py; 3 or 4 for tighter)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` object (c3, c4 and the BitNet32-F16 prefill measured after the c2 line, same process)")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the step graph")
     ap.add_argument("--c5-timeout", type=float, default=240.0, help="N > 1: seconds the token-parallel prefill part may take before the line is printed without it")
     ap.add_argument("--gguf", default=None, help="a real model file instead of synthetic weights (default: $BITNET_GGUF if set); the line then says data: gguf")
@@ -605,6 +748,12 @@ def main():
                               "prefill_check": prefill_chk, "roofline": prefill_roof}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
+    if n_gpus == 1 and args.workload == "c2" and not args.no_also and not gguf and not args.layers and not args.exact_act:
+        dec.close()  # the headline model's memory goes back first
+        try:
+            out["also"] = also_workloads(args, pkg, synth, hip, use_graph)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, never in the way of the headline numbers
+            out["also"] = {"error": f"{type(e).__name__}: {e}"}
     # N > 1: the decode line above is N independent replicas (batch-1 decode does not shard); the path's ONE real collective
     # -- the token-parallel prefill of BASELINE configs[4] -- runs here too, over the same ranks, and rides in the same line
     c5 = None

@@ -761,6 +761,18 @@ class HostDecoder:
                                                   int(wire_f16), C.byref(ms)))
         return ms.value
 
+    def set_phase_timing(self, on: bool) -> None:
+        """per-phase event timing of the next prefill_sharded calls (8 event records per layer)"""
+        self.c.bitnet_host_set_phase_timing.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.c.bitnet_host_set_phase_timing(self.h, int(on)))
+
+    def phase_times(self) -> dict:
+        """medians over the layers of the last timed prefill_sharded call, microseconds per layer"""
+        out = (C.c_float * 4)()
+        self.c.bitnet_host_phase_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self._check(self.c.bitnet_host_phase_times(self.h, out))
+        return {"matmul_us": round(out[0], 1), "attention_us": round(out[1], 1), "gather_wait_us": round(out[2], 1), "gather_us": round(out[3], 1)}
+
     def prefill(self, n: int, with_logits: bool = True, digits: int = 4) -> float:
         self.c.bitnet_host_prefill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         ms = C.c_float(0)

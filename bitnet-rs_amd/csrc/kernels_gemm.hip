@@ -293,14 +293,22 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
 
 // CW = wave columns: 2 (8 waves, 256 rows x 2 TTW token tiles) or 1 (4 waves, 256 rows x TTW token tiles; with MINW = 2 two such
 // workgroups share a CU with independent barriers at the full register budget).
-template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2>
-__global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
+// RW = wave rows: 4 (256 weight rows per workgroup) or 8 (512 rows: the activation tile -- the larger of the two streams a workgroup
+// stages, 2 bytes per (token, column) against 2 bits per weight -- is fetched and written to LDS once per 32 row tiles instead of
+// once per 16: half the staging loads / LDS stores per MFMA).
+// VAR (unscaled form only): 0 = hipcc's own schedule; 1 = the next step's global loads fenced to the TOP of the step (hipcc sinks
+// them to the end of the loop body, where they are waited for a barrier later: a global round trip exposed per K step);
+// 2 = 1 + the B-operand reads of tile pair p + 1 issued ahead of the MFMAs of pair p, fenced (hipcc waits for every pair of
+// reads right after issuing them: an LDS round trip exposed per 8 MFMAs).
+template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2, int RW = 4, int VAR = 0>
+__global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
     constexpr int WG_COLS = CW * CT * 16;           // plane rows per workgroup
-    constexpr int NB = WG_COLS * 16 / (256 * CW);   // uint4 per thread per K step
+    constexpr int NTHR = 64 * RW * CW;
+    constexpr int NB = WG_COLS * 16 / NTHR;         // uint4 per thread per K step
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, g = lane >> 4, rw = wave & 3, cw = wave >> 2;
+    const int c = lane & 15, g = lane >> 4, rw = wave % RW, cw = wave / RW;
     const int n_tiles = (p.rows + 15) >> 4;
     const int kp = p.nblk * 256;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that one XCD
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     const uint8_t *wptr[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        int t = bx * 16 + rw * 4 + rt;
+        int t = bx * (4 * RW) + rw * 4 + rt;
         t = t < n_tiles ? t : n_tiles - 1;
         wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
     }
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     int bdst[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int idx = tid + 256 * CW * i, col = idx >> 4, seg = idx & 15;
+        const int idx = tid + NTHR * i, col = idx >> 4, seg = idx & 15;
         bsrc[i] = p.planes + (size_t)(by * WG_COLS + col) * kp + seg * 16;
         bdst[i] = col * CSTR + (WS == 3 ? seg : seg ^ col_swz(col & 15)) * 16;
     }
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     if (WS == 2) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            int t = bx * 16 + rw * 4 + rt;
+            int t = bx * (4 * RW) + rw * 4 + rt;
             t = t < n_tiles ? t : n_tiles - 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     if (WS == 3) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            int t = bx * 16 + rw * 4 + rt;
+            int t = bx * (4 * RW) + rw * 4 + rt;
             t = t < n_tiles ? t : n_tiles - 1;
             sptr[rt] = p.stiles_h + (size_t)t * p.nblk * 128 + 8 * g;
             scn[rt] = *reinterpret_cast<const gv4u *>(sptr[rt]);
@@ -445,6 +453,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 256);
 #endif
+            if (VAR >= 1) __builtin_amdgcn_sched_barrier(0);  // keep the next step's loads AHEAD of this step's MFMAs
         }
         if (WS == 3) {
 #pragma unroll
@@ -498,6 +507,43 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
                         }
                     }
                 }
+            }
+        } else if (WS != 2 && VAR >= 2 && (CT % 2) == 0) {
+            // explicit order: [reads of pair p + 1] | [8 MFMAs of pair p + the expansion of one row tile of the next dword]
+            constexpr int NP = CT / 2;  // tile pairs per dword
+            v4i bq[4], a[4], an[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) a[rt] = gdecode16(wc[rt].x, p.lut);
+            bq[0] = *reinterpret_cast<const v4i *>(bcur + moff[0]);
+            bq[1] = *reinterpret_cast<const v4i *>(bcur + 16 * CSTR + moff[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int pr = 0; pr < NP; ++pr) {
+                    const int u = m * NP + pr, s0 = 2 * (u & 1), s1 = 2 * ((u + 1) & 1);  // this pair's slots, the next pair's
+                    const int nm = pr + 1 < NP ? m : m + 1, np_ = pr + 1 < NP ? pr + 1 : 0;
+                    if (nm < 4) {
+                        bq[s1] = *reinterpret_cast<const v4i *>(bcur + (2 * np_) * 16 * CSTR + moff[nm]);
+                        bq[s1 + 1] = *reinterpret_cast<const v4i *>(bcur + (2 * np_ + 1) * 16 * CSTR + moff[nm]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt)
+                            acc[rt][2 * pr + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], bq[s0 + h], acc[rt][2 * pr + h], 0, 0, 0);
+                    if (m + 1 < 4) {  // the next dword's A operands, one row tile (or more, when there are fewer pairs) per pair
+#pragma unroll
+                        for (int rt = pr * 4 / NP; rt < (pr + 1) * 4 / NP; ++rt) {
+                            const uint32_t wd = m + 1 == 1 ? wc[rt].y : m + 1 == 2 ? wc[rt].z : wc[rt].w;
+                            an[rt] = gdecode16(wd, p.lut);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) a[rt] = an[rt];
             }
         } else if (WS != 2) {
 #pragma unroll
@@ -569,7 +615,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
             // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                int t = bx * 16 + rw * 4 + rt;
+                int t = bx * (4 * RW) + rw * 4 + rt;
                 t = t < n_tiles ? t : n_tiles - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -595,7 +641,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[rt][j] = (WS ? facc[rt][tt][j] : combine_digits<NDIG>(&acc[rt][tt * NDIG], j)) * is;
-        store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
+        store_wave_tiles(p, val, tok0, c, g, bx * (4 * RW) + rw * 4);
     }
 }
 
@@ -861,7 +907,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
     constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
     void (*gk)(GemmArgs) = k32 ? k_gemm_mfma<NDIG, TT32, 3> : !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS, cw = 2;
+    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS, cw = 2, rw = 4;
     const bool scaled_variant = a.wscale || k32;
     // 4-wave workgroups (256 rows x TTW token tiles) bounded to two waves per SIMD: two workgroups share a CU with independent
     // barriers (one stages its next tile while the other multiplies) at the full register budget, and a 2560-row matrix x
@@ -878,6 +924,17 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             ttw = gemm_token_tiles(gx0, q.m_pad, true);
             if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
             if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
+            // 512-row workgroups (8 waves, one workgroup per CU) where they still cover the chip twice over
+            static const int rw8_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_RW8"); return e ? atoi(e) : 0; }();
+            static const int var_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_VAR"); return e ? atoi(e) : 0; }();
+            if (rw8_mode && ttw == 4 && div_ceil(gx0, 2) * (q.m_pad / 64) >= 2 * kGemmCUs) {
+                gk = var_mode == 2 ? k_gemm_mfma<2, 4, 0, 1, 1, 8, 2> : var_mode == 1 ? k_gemm_mfma<2, 4, 0, 1, 1, 8, 1> : k_gemm_mfma<2, 4, 0, 1, 1, 8>;
+                rw = 8;
+            } else if (ttw == 4 && var_mode) {
+                gk = var_mode == 2 ? k_gemm_mfma<2, 4, 0, 2, 1, 4, 2> : k_gemm_mfma<2, 4, 0, 2, 1, 4, 1>;
+            } else if (ttw == 2 && var_mode) {
+                gk = var_mode == 2 ? k_gemm_mfma<2, 2, 0, 2, 1, 4, 2> : k_gemm_mfma<2, 2, 0, 2, 1, 4, 1>;
+            }
         }
     }
     const size_t lds = (size_t)cw * NDIG * ttw * 16 * (k32 ? kColStride : 256) * (scaled_variant ? 1 : 2) + (k32 ? (size_t)4 * cw * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
@@ -892,9 +949,9 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             raised.insert((const void *)gk);
         }
     }
-    g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, 4 * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
-    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
-    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, a);
+    g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, rw * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
+    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 4 * (size_t)rw), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
+    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(64 * rw * cw), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 namespace bitnet_host {
 
@@ -175,6 +177,8 @@ Decoder::~Decoder() {
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_, sp_kv_send_, sp_kv_all_,
                     (void *)sp_block_pos_, (void *)sp_tokens_})
         if (p) hipFree(p);
+    for (void *e : sp_tev_)
+        if (e) hipEventDestroy((hipEvent_t)e);
     if (sp_ev_pack_) hipEventDestroy((hipEvent_t)sp_ev_pack_);
     if (sp_ev_gather_) hipEventDestroy((hipEvent_t)sp_ev_gather_);
     if (comm_stream_) hipStreamDestroy((hipStream_t)comm_stream_);
@@ -886,38 +890,79 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
     Event ev0, ev1;
     HCHK(hipEventCreate(&ev0.e));
     HCHK(hipEventCreate(&ev1.e));
+    // optional per-phase timing: 8 events per layer (6 on the compute stream, 2 around the collective on its own stream)
+    const bool timing = sp_timing_;
+    if (timing && sp_tev_.size() < layers_.size() * 8) {
+        const size_t want = layers_.size() * 8;
+        while (sp_tev_.size() < want) {
+            hipEvent_t e = nullptr;
+            HCHK(hipEventCreate(&e));
+            sp_tev_.push_back(e);
+        }
+    }
+    size_t li = 0;
+    auto mark = [&](int idx, hipStream_t st) -> hipError_t { return timing ? hipEventRecord((hipEvent_t)sp_tev_[li * 8 + (size_t)idx], st) : hipSuccess; };
     HCHK(hipEventRecord(ev0.e, s));
     BCHK(bitnet_hip_embed_f16_dev(embed_, sp_tokens_, nullptr, N, H, (size_t)c_.vocab, pf_x_, s));
     const size_t ld = QD + 2 * KD, per_rank = N * 2 * KD * esz;
     for (auto &L : layers_) {
+        HCHK(mark(0, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         // the raw (pre-RoPE) k|v rows this rank contributes, compact, f32 or f16
         BCHK(bitnet_hip_pack_cols_dev(pf_qkv_, ld, QD, 2 * KD, N, world > 1 ? sp_kv_send_ : sp_kv_all_, wire_f16 ? 1 : 0, s));
+        HCHK(mark(1, s));
         if (world > 1) {
             // the collective runs on its own stream beside the query-side preparation (RoPE + f16 pack of this rank's q rows);
             // the k / v slabs and the attention follow once it has finished
             HCHK(hipEventRecord((hipEvent_t)sp_ev_pack_, s));
             HCHK(hipStreamWaitEvent((hipStream_t)comm_stream_, (hipEvent_t)sp_ev_pack_, 0));
+            HCHK(mark(6, (hipStream_t)comm_stream_));
             if (gather(gather_ctx, sp_kv_send_, sp_kv_all_, per_rank, comm_stream_) != 0) {
                 err_ = "prefill_sharded: the all-gather callback failed";
                 return BITNET_HIP_ERR_EXECUTION;
             }
+            HCHK(mark(7, (hipStream_t)comm_stream_));
             HCHK(hipEventRecord((hipEvent_t)sp_ev_gather_, (hipStream_t)comm_stream_));
             BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
                                                                  rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, 1, s));
+            HCHK(mark(2, s));
             HCHK(hipStreamWaitEvent(s, (hipEvent_t)sp_ev_gather_, 0));
+            HCHK(mark(3, s));
+        } else {
+            HCHK(mark(2, s));
+            HCHK(mark(3, s));
+            HCHK(mark(6, s));
+            HCHK(mark(7, s));
         }
         BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
                                                              rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_,
                                                              world > 1 ? 2 : 0, s));
+        HCHK(mark(4, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        HCHK(mark(5, s));
+        ++li;
     }
     {
-        // the last prompt position sits in chunk 2 world - 1 = rank 0's second chunk: its last local row
-        const int rc = finish_prefill(n, rank == 0 ? pf_x_ + (N - 1) * H : nullptr, with_logits);
+        // The last prompt position sits in chunk 2 world - 1 = rank 0's second chunk: its last local row.  EVERY rank gets that row
+        // (one more gather of `hidden` floats per rank through the same callback and stream ties: slot 0 is rank 0's), so any rank can
+        // continue decoding -- with logits and the first sampled token -- on the cache it filled.
+        const float *last = pf_x_ + (N - 1) * H;
+        if (world > 1) {
+            HCHK(hipMemcpyAsync(sp_kv_send_, last, H * 4, hipMemcpyDeviceToDevice, s));
+            HCHK(hipEventRecord((hipEvent_t)sp_ev_pack_, s));
+            HCHK(hipStreamWaitEvent((hipStream_t)comm_stream_, (hipEvent_t)sp_ev_pack_, 0));
+            if (gather(gather_ctx, sp_kv_send_, sp_kv_all_, H * 4, comm_stream_) != 0) {
+                err_ = "prefill_sharded: the all-gather callback failed (last row)";
+                return BITNET_HIP_ERR_EXECUTION;
+            }
+            HCHK(hipEventRecord((hipEvent_t)sp_ev_gather_, (hipStream_t)comm_stream_));
+            HCHK(hipStreamWaitEvent(s, (hipEvent_t)sp_ev_gather_, 0));
+            last = static_cast<const float *>(sp_kv_all_);
+        }
+        const int rc = finish_prefill(n, last, with_logits);
         if (rc) return rc;
     }
     HCHK(hipEventRecord(ev1.e, s));
@@ -925,6 +970,25 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, ev0.e, ev1.e));
     if (elapsed_ms) *elapsed_ms = ms;
+    if (timing) {
+        if (comm_stream_) HCHK(hipStreamSynchronize((hipStream_t)comm_stream_));
+        std::vector<float> ph[4];
+        for (size_t l = 0; l < layers_.size(); ++l) {
+            auto dt = [&](int a, int b) {
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, (hipEvent_t)sp_tev_[l * 8 + (size_t)a], (hipEvent_t)sp_tev_[l * 8 + (size_t)b]);
+                return t * 1e3f;
+            };
+            ph[0].push_back(dt(0, 1) + dt(4, 5));
+            ph[1].push_back(dt(1, 2) + dt(3, 4));
+            ph[2].push_back(dt(2, 3));
+            ph[3].push_back(dt(6, 7));
+        }
+        for (int i = 0; i < 4; ++i) {
+            std::sort(ph[i].begin(), ph[i].end());
+            sp_phase_us_[i] = ph[i].empty() ? 0.f : ph[i][ph[i].size() / 2];
+        }
+    }
     return 0;
 }
 
@@ -1173,6 +1237,17 @@ int bitnet_host_rccl_allgather(void *nccl_comm, const void *send_dev, void *recv
     }();
     if (!fn || !nccl_comm) return -1;
     return fn(send_dev, recv_dev, bytes_per_rank, /* ncclUint8 */ 1, nccl_comm, stream);
+}
+int bitnet_host_set_phase_timing(void *d, int on) {
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    D->set_phase_timing(on != 0);
+    return 0;
+}
+int bitnet_host_phase_times(void *d, float out[4]) {
+    LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);
+    if (!out) return BITNET_HIP_ERR_INVALID_ARGUMENT;
+    D->phase_times(out);
+    return 0;
 }
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits) {
     LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT);

@@ -114,6 +114,10 @@ class Decoder {
     // the KV cache already holds positions 0..n-1; last_row (device, [hidden]) is the residual stream
     // of position n-1 or null on ranks that do not own it (then only the position counter moves).
     int finish_prefill(int n, const float *last_row, bool with_logits);
+    void set_phase_timing(bool on) { sp_timing_ = on; }
+    void phase_times(float out[4]) const {
+        for (int i = 0; i < 4; ++i) out[i] = sp_phase_us_[i];
+    }
     // Device objects of one layer / of the model for such a driver: handles {qkv, o, gate|up, down},
     // pointers {attn_norm, ffn_norm, kcache, vcache}; globals {embed, final_norm, rope_sin, rope_cos,
     // history, pos, stream}.
@@ -189,6 +193,12 @@ class Decoder {
     void *sp_kv_send_ = nullptr, *sp_kv_all_ = nullptr;
     void *comm_stream_ = nullptr, *sp_ev_pack_ = nullptr, *sp_ev_gather_ = nullptr;  // the all-gather's own stream and its two ties to the compute stream
     int32_t *sp_block_pos_ = nullptr, *sp_tokens_ = nullptr;
+    // per-phase timing of the sharded prefill (set_phase_timing): 8 timing events per layer on the compute / comm streams, and the
+    // medians over the layers of the last timed call: [0] projections (q|k|v + pack, o, gate|up, down), [1] attention (both phases),
+    // [2] the part of the all-gather the compute stream had to wait for, [3] the all-gather itself on its own stream; microseconds
+    bool sp_timing_ = false;
+    std::vector<void *> sp_tev_;
+    float sp_phase_us_[4] = {0.f, 0.f, 0.f, 0.f};
     // prefill buffers (grown on demand)
     int pf_cap_ = 0;
     float *pf_x_ = nullptr, *pf_qkv_ = nullptr, *pf_att_ = nullptr, *pf_h_ = nullptr;
@@ -228,6 +238,10 @@ int bitnet_host_set_kv_f16(void *d, int on);
 int bitnet_host_act_mode(void *d);
 int bitnet_host_prefill(void *d, int n, int with_logits, int digits, float *elapsed_ms);
 int bitnet_host_finish_prefill(void *d, int n, const float *last_row, int with_logits);
+// per-phase medians of the NEXT bitnet_host_prefill_sharded calls (off by default: 8 event records per layer); out[4] = projections,
+// attention, exposed all-gather wait, all-gather on its own stream -- microseconds per layer, medians over the layers of the last call
+int bitnet_host_set_phase_timing(void *d, int on);
+int bitnet_host_phase_times(void *d, float out[4]);
 int bitnet_host_prefill_sharded(void *d, int n, int rank, int world, bitnet_host_allgather_fn gather, void *gather_ctx, int with_logits,
                                 int digits, int wire_f16, float *elapsed_ms);
 // ncclAllGather on an existing RCCL communicator (ctx = ncclComm_t), resolved from librccl.so at first use: the host library

@@ -147,6 +147,98 @@ void bo_attention_decode(const float *q, const float *kc, const float *vc, int n
     free(scores);
 }
 
+/* The same arithmetic with the HEADS dealt to threads: a head's scores, softmax and weighted sum are computed by one thread in
+ * the order above, so every output element is bit-identical to bo_attention_decode (heads are independent: T:426-533 loops
+ * over them).  Test infrastructure for long contexts (4096-token oracle runs), not a different algorithm. */
+struct attn_arg {
+    const float *q, *kc, *vc;
+    int n_heads, n_kv_heads, dim, max_pos, t_k, h0, h1;
+    float *out;
+};
+static void *attn_worker(void *p) {
+    struct attn_arg *a = (struct attn_arg *)p;
+    int group = a->n_heads / a->n_kv_heads, dim = a->dim, t_k = a->t_k;
+    float scale = 1.0f / sqrtf((float)dim);
+    float *scores = (float *)malloc(sizeof(float) * (size_t)t_k);
+    for (int h = a->h0; h < a->h1; ++h) {
+        int kvh = h / group;
+        const float *qh = a->q + (size_t)h * dim;
+        const float *kh = a->kc + (size_t)kvh * a->max_pos * dim;
+        const float *vh = a->vc + (size_t)kvh * a->max_pos * dim;
+        float mx = -INFINITY;
+        for (int j = 0; j < t_k; ++j) {
+            float s = 0.0f;
+            for (int d = 0; d < dim; ++d) s += qh[d] * kh[(size_t)j * dim + d];
+            s = s * scale;
+            scores[j] = s;
+            if (s > mx) mx = s;
+        }
+        float sum = 0.0f;
+        for (int j = 0; j < t_k; ++j) {
+            scores[j] = expf(scores[j] - mx);
+            sum += scores[j];
+        }
+        for (int d = 0; d < dim; ++d) {
+            float acc = 0.0f;
+            for (int j = 0; j < t_k; ++j) acc += (scores[j] / sum) * vh[(size_t)j * dim + d];
+            a->out[(size_t)h * dim + d] = acc;
+        }
+    }
+    free(scores);
+    return NULL;
+}
+void bo_attention_decode_mt(const float *q, const float *kc, const float *vc, int n_heads, int n_kv_heads, int dim,
+                            int max_pos, int t_k, float *out, int n_threads) {
+    if (n_threads < 2 || t_k < 128) {
+        bo_attention_decode(q, kc, vc, n_heads, n_kv_heads, dim, max_pos, t_k, out);
+        return;
+    }
+    pthread_t th[64];
+    struct attn_arg args[64];
+    int nt = n_threads > 64 ? 64 : n_threads;
+    if (nt > n_heads) nt = n_heads;
+    int per = (n_heads + nt - 1) / nt;
+    int used = 0;
+    for (int t = 0; t < nt; ++t) {
+        int h0 = t * per, h1 = h0 + per > n_heads ? n_heads : h0 + per;
+        if (h0 >= h1) break;
+        args[t] = (struct attn_arg){q, kc, vc, n_heads, n_kv_heads, dim, max_pos, t_k, h0, h1, out};
+        pthread_create(&th[t], NULL, attn_worker, &args[t]);
+        ++used;
+    }
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+}
+
+/* dense f32 projection, rows dealt to threads: each row's dot product is the loop of proj() below, bit for bit */
+struct dense_arg {
+    const float *W, *x;
+    float *y;
+    int r0, r1, cols;
+};
+static void *dense_worker(void *p) {
+    struct dense_arg *a = (struct dense_arg *)p;
+    for (int r = a->r0; r < a->r1; ++r) {
+        float acc = 0.0f;
+        for (int c = 0; c < a->cols; ++c) acc += a->x[c] * a->W[(size_t)r * a->cols + c];
+        a->y[r] = acc;
+    }
+    return NULL;
+}
+static void dense_mt(const float *W, const float *x, float *y, int rows, int cols, int n_threads) {
+    pthread_t th[64];
+    struct dense_arg args[64];
+    int nt = n_threads > 64 ? 64 : n_threads;
+    int per = (rows + nt - 1) / nt, used = 0;
+    for (int t = 0; t < nt; ++t) {
+        int r0 = t * per, r1 = r0 + per > rows ? rows : r0 + per;
+        if (r0 >= r1) break;
+        args[t] = (struct dense_arg){W, x, y, r0, r1, cols};
+        pthread_create(&th[t], NULL, dense_worker, &args[t]);
+        ++used;
+    }
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+}
+
 void *bo_model_create(const bo_model_cfg *cfg, int n_threads) {
     bo_model *m = (bo_model *)calloc(1, sizeof(bo_model));
     m->cfg = *cfg;
@@ -227,6 +319,10 @@ static int proj(const bo_model *m, const bo_layer *L, int which, const uint8_t *
                 int cols) {
     if (L->dense[which]) { /* x . W^T, one f32 dot product per output */
         const float *W = L->dense[which];
+        if (m->n_threads > 1 && rows >= 256) {
+            dense_mt(W, x, y, rows, cols, m->n_threads);
+            return 0;
+        }
         for (int r = 0; r < rows; ++r) {
             float acc = 0.0f;
             for (int c = 0; c < cols; ++c) acc += x[c] * W[(size_t)r * cols + c];
@@ -317,7 +413,7 @@ int bo_model_step(void *mp, void *kvp, int token, float *hidden_out, float *logi
             memcpy(kc + ((size_t)h * c->max_pos + pos) * D, kx + (size_t)h * D, sizeof(float) * (size_t)D);
             memcpy(vc + ((size_t)h * c->max_pos + pos) * D, vx + (size_t)h * D, sizeof(float) * (size_t)D);
         }
-        bo_attention_decode(q, kc, vc, NH, NKV, D, c->max_pos, pos + 1, att);
+        bo_attention_decode_mt(q, kc, vc, NH, NKV, D, c->max_pos, pos + 1, att, m->n_threads);
         rc |= proj(m, L, 3, L->o, att, tmp, H, NH * D);
         for (int i = 0; i < H; ++i) x[i] = tmp[i] + x[i]; /* x + residual T:1073 */
         bo_layernorm(x, L->ffn_norm, c->eps, H, xn);

@@ -229,17 +229,28 @@ def test_full_size_matmul_properties_are_bit_exact(hip, torch_, layers, fmt, nam
 
 @pytest.mark.parametrize("fmt", ["qk256", "i2s"])
 def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle, synth, fmt):
+    """c4's regime end to end against the ORACLE: the oracle's token-by-token model (oracle/transformer_oracle.c,
+    T:398-543 attention over an f32 cache T:1171-1202, 16 host threads dealing heads / rows: bit-identical to one thread,
+    tests/test_oracle_threads.py) walks the 4096-token prompt once; on the way it leaves the logits at position 1023 and, at the end, the
+    logits of 3 greedy tokens from position 4095 on.  The HIP decoder is then held to them:
+      * prefill(1024, digits = 2) (gate|up on the wide tile, the 2560-row launches on narrower ones);
+      * prefill(4096, digits = 2) -- EVERY launch on the benchmarked tile -- then 2 decode steps at 4097 / 4098 keys, f32 KV cache;
+      * the same with the f16 KV cache (bench.py's c4 default): the decode steps run k_attn_partial<2, true> + k_attn_combine<5>,
+        the 128-position f16 form the decoder takes beyond 256 chunk records (5 KV heads x 65 chunks);
+    logits cosine >= 0.9999 each, the same greedy tokens."""
     cfg = synth.ModelConfig(**WIDE)
     glob, layers, olayers = _models(synth, fmt, cfg)
-    n_prompt, n_new = 1024, 3
-    prompt = synth.prompt(4096, cfg.vocab)
+    T, n_new = 4096, 3
+    prompt = synth.prompt(T, cfg.vocab)
     om = oracle.OracleModel(cfg, olayers, glob, n_threads=16)
-    seq = list(prompt[:n_prompt])
-    o_logits = []
-    for p in range(n_prompt + n_new - 1):
-        _, logits, _ = om.step(seq[p], want_logits=p >= n_prompt - 1)
-        if p >= n_prompt - 1:
-            o_logits.append(logits)
+    seq = list(prompt)
+    o_logits, o_1k = [], None
+    for p in range(T + n_new - 1):
+        _, logits, _ = om.step(seq[p], want_logits=p >= T - 1 or p == 1023)
+        if p == 1023:
+            o_1k = logits.copy()
+        if p >= T - 1:
+            o_logits.append(logits.copy())
             seq.append(oracle.argmax(logits))
     om.close()
     dec = pkg.HostDecoder(cfg)
@@ -247,28 +258,29 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
         dec.set_layer_qk256(l, w) if fmt == "qk256" else dec.set_layer_i2s(l, w, 32)
     dec.set_globals(glob)
     dec.reset()
-    dec.feed(prompt[:n_prompt])
-    dec.prefill(n_prompt, with_logits=True, digits=2)
+    dec.feed(prompt[:1024])
+    dec.prefill(1024, with_logits=True, digits=2)
     t = hip.matmul_last_tile()  # the last launch of the loop is a 2560-row down-projection: narrower tile at 1024 rows (QK256)
     assert t["digits"] == 2 and t["scale_mode"] == (0 if fmt == "qk256" else 4)
-    assert dec.position() == n_prompt
-    c = cosine(dec.last_logits(), o_logits[0])
+    assert dec.position() == 1024
+    c = cosine(dec.last_logits(), o_1k)
     assert c >= 0.9999, c
-    for i in range(1, n_new):
-        dec.run(1, with_logits=True, use_graph=True)
-        c = cosine(dec.last_logits(), o_logits[i])
-        assert c >= 0.9999, (i, c)
-    assert list(dec.history(n_prompt + n_new)) == [int(t) for t in seq]
-    # 4096 tokens: every launch takes the benchmarked tile; against the oracle-pinned 4-digit prefill of the same prompt
-    out = {}
-    for digits in (4, 2):
+    hidden = {}
+    for kv16 in (False, True):
         dec.reset()
-        dec.feed(prompt)
-        dec.prefill(4096, with_logits=True, digits=digits)
+        dec.set_kv_f16(kv16)
+        dec.feed(seq)  # every token forced to the oracle's
+        dec.prefill(T, with_logits=True, digits=2)
         tile = hip.matmul_last_tile()
-        out[digits] = (dec.last_logits().copy(), int(dec.history(4097)[4096]), dec.last_hidden().copy())
-    assert tile == expect_tile(fmt, "down_residual"), tile  # the prompt's last matmul is a down-projection
-    assert cosine(out[2][0], out[4][0]) >= 0.9999
-    assert cosine(out[2][2], out[4][2]) >= 0.9999
-    assert out[2][1] == out[4][1]
+        assert tile == expect_tile(fmt, "down_residual"), tile  # the prompt's last matmul is a down-projection
+        assert dec.position() == T
+        c = cosine(dec.last_logits(), o_logits[0])
+        assert c >= 0.9999, (kv16, c)
+        hidden[kv16] = dec.last_hidden().copy()
+        for i in range(1, n_new):
+            dec.run(1, with_logits=True, use_graph=True)  # keys 4097, 4098: the wide (128-position) attention form
+            c = cosine(dec.last_logits(), o_logits[i])
+            assert c >= 0.9999, (kv16, i, c)
+        assert list(dec.history(T + n_new)) == [int(t) for t in seq], kv16
+    assert cosine(hidden[False], hidden[True]) >= 0.99999  # the prompt attention is f16 on the matrix cores either way
     dec.close()

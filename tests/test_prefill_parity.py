@@ -263,7 +263,9 @@ def test_prefill_attention_is_causal_and_block_independent(hip, oracle, torch_):
                                       wsb2, out)
     torch_.cuda.synchronize()
     # (the two launches split a query block's key tiles over different numbers of workgroups: equal up to the f32 merge's rounding)
-    assert np.max(np.abs(out.cpu().numpy() - base[rows])) <= 1e-3 * np.max(np.abs(base))  # the probabilities are rounded to f16 against each part's own running maximum
+    # the probabilities are rounded to f16 against each key part's own running maximum: observed 6.7e-5 of max|base| when the key-split
+    # form landed (gpurun_out/r3_t9.log); the gate is 3x that -- a wrong merge weight shows up at 1e-2 and more
+    assert np.max(np.abs(out.cpu().numpy() - base[rows])) <= 2e-4 * np.max(np.abs(base))
 
 
 MANYKV = dict(hidden=1024, n_layers=2, n_heads=8, n_kv_heads=8, head_dim=128, ffn=1024, vocab=2048, max_pos=2176, eps=1e-5, rope_theta=10000.0)
@@ -369,6 +371,11 @@ def test_cpp_sharded_prefill_two_ranks_one_gpu(pkg, hip, synth, torch_, world, T
     assert list(d0.history(T + 4)) == want_tokens or wire_f16
     for d in decs[1:]:
         assert d.position() == T
+        # every rank received the last prompt position's row with the closing gather: same logits, and it decodes on from its own cache
+        assert np.array_equal(d.last_logits(), got)
+    if world > 1:
+        decs[-1].run(3, with_logits=True)
+        assert list(decs[-1].history(T + 4)) == list(d0.history(T + 4))
     for d in decs:
         d.close()
     with pytest.raises(pkg.BitNetHipError, match="multiple of"):
@@ -501,7 +508,7 @@ def test_gathered_attention_world8_8k_matches_unsharded_and_f64(hip, oracle, tor
         got = out.cpu().numpy()
         assert not np.isnan(got).any()
         if not wire_f16:
-            assert np.max(np.abs(got - base[rows])) <= 1e-3 * np.max(np.abs(base)), rank  # key splits differ (8 parts here, 1 there): f16 probabilities against each part's own maximum
+            assert np.max(np.abs(got - base[rows])) <= 2e-4 * np.max(np.abs(base)), rank  # key splits differ (8 parts here, 1 there): f16 probabilities against each part's own maximum (observed 6.7e-5)
             assert torch_.equal(kc, kc0) and torch_.equal(vc, vc0), rank  # every rank fills the whole cache
         else:
             assert np.max(np.abs(got - base[rows])) <= 6e-3 and cosine(got, base[rows]) >= 0.99999, rank
