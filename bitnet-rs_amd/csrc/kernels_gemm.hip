@@ -293,22 +293,14 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
 
 // CW = wave columns: 2 (8 waves, 256 rows x 2 TTW token tiles) or 1 (4 waves, 256 rows x TTW token tiles; with MINW = 2 two such
 // workgroups share a CU with independent barriers at the full register budget).
-// RW = wave rows: 4 (256 weight rows per workgroup) or 8 (512 rows: the activation tile -- the larger of the two streams a workgroup
-// stages, 2 bytes per (token, column) against 2 bits per weight -- is fetched and written to LDS once per 32 row tiles instead of
-// once per 16: half the staging loads / LDS stores per MFMA).
-// VAR (unscaled form only): 0 = hipcc's own schedule; 1 = the next step's global loads fenced to the TOP of the step (hipcc sinks
-// them to the end of the loop body, where they are waited for a barrier later: a global round trip exposed per K step);
-// 2 = 1 + the B-operand reads of tile pair p + 1 issued ahead of the MFMAs of pair p, fenced (hipcc waits for every pair of
-// reads right after issuing them: an LDS round trip exposed per 8 MFMAs).
-template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2, int RW = 4, int VAR = 0>
-__global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
+template <int NDIG, int TTW, int WS, int MINW = 1, int CW = 2>
+__global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     constexpr int CT = NDIG * TTW;          // B tiles per wave
     constexpr int WG_COLS = CW * CT * 16;           // plane rows per workgroup
-    constexpr int NTHR = 64 * RW * CW;
-    constexpr int NB = WG_COLS * 16 / NTHR;         // uint4 per thread per K step
+    constexpr int NB = WG_COLS * 16 / (256 * CW);   // uint4 per thread per K step
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, g = lane >> 4, rw = wave % RW, cw = wave / RW;
+    const int c = lane & 15, g = lane >> 4, rw = wave & 3, cw = wave >> 2;
     const int n_tiles = (p.rows + 15) >> 4;
     const int kp = p.nblk * 256;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that one XCD
@@ -328,7 +320,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     const uint8_t *wptr[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        int t = bx * (4 * RW) + rw * 4 + rt;
+        int t = bx * 16 + rw * 4 + rt;
         t = t < n_tiles ? t : n_tiles - 1;
         wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
     }
@@ -338,7 +330,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     int bdst[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int idx = tid + NTHR * i, col = idx >> 4, seg = idx & 15;
+        const int idx = tid + 256 * CW * i, col = idx >> 4, seg = idx & 15;
         bsrc[i] = p.planes + (size_t)(by * WG_COLS + col) * kp + seg * 16;
         bdst[i] = col * CSTR + (WS == 3 ? seg : seg ^ col_swz(col & 15)) * 16;
     }
@@ -381,7 +373,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     if (WS == 2) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            int t = bx * (4 * RW) + rw * 4 + rt;
+            int t = bx * 16 + rw * 4 + rt;
             t = t < n_tiles ? t : n_tiles - 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -401,7 +393,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
     if (WS == 3) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            int t = bx * (4 * RW) + rw * 4 + rt;
+            int t = bx * 16 + rw * 4 + rt;
             t = t < n_tiles ? t : n_tiles - 1;
             sptr[rt] = p.stiles_h + (size_t)t * p.nblk * 128 + 8 * g;
             scn[rt] = *reinterpret_cast<const gv4u *>(sptr[rt]);
@@ -453,7 +445,6 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 256);
 #endif
-            if (VAR >= 1) __builtin_amdgcn_sched_barrier(0);  // keep the next step's loads AHEAD of this step's MFMAs
         }
         if (WS == 3) {
 #pragma unroll
@@ -507,43 +498,6 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
                         }
                     }
                 }
-            }
-        } else if (WS != 2 && VAR >= 2 && (CT % 2) == 0) {
-            // explicit order: [reads of pair p + 1] | [8 MFMAs of pair p + the expansion of one row tile of the next dword]
-            constexpr int NP = CT / 2;  // tile pairs per dword
-            v4i bq[4], a[4], an[4];
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) a[rt] = gdecode16(wc[rt].x, p.lut);
-            bq[0] = *reinterpret_cast<const v4i *>(bcur + moff[0]);
-            bq[1] = *reinterpret_cast<const v4i *>(bcur + 16 * CSTR + moff[0]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int pr = 0; pr < NP; ++pr) {
-                    const int u = m * NP + pr, s0 = 2 * (u & 1), s1 = 2 * ((u + 1) & 1);  // this pair's slots, the next pair's
-                    const int nm = pr + 1 < NP ? m : m + 1, np_ = pr + 1 < NP ? pr + 1 : 0;
-                    if (nm < 4) {
-                        bq[s1] = *reinterpret_cast<const v4i *>(bcur + (2 * np_) * 16 * CSTR + moff[nm]);
-                        bq[s1 + 1] = *reinterpret_cast<const v4i *>(bcur + (2 * np_ + 1) * 16 * CSTR + moff[nm]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int rt = 0; rt < 4; ++rt)
-                            acc[rt][2 * pr + h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rt], bq[s0 + h], acc[rt][2 * pr + h], 0, 0, 0);
-                    if (m + 1 < 4) {  // the next dword's A operands, one row tile (or more, when there are fewer pairs) per pair
-#pragma unroll
-                        for (int rt = pr * 4 / NP; rt < (pr + 1) * 4 / NP; ++rt) {
-                            const uint32_t wd = m + 1 == 1 ? wc[rt].y : m + 1 == 2 ? wc[rt].z : wc[rt].w;
-                            an[rt] = gdecode16(wd, p.lut);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) a[rt] = an[rt];
             }
         } else if (WS != 2) {
 #pragma unroll
@@ -615,7 +569,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
             // one f32 weight scale per (row, 256-block): fold this block's exact sums into f32
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                int t = bx * (4 * RW) + rw * 4 + rt;
+                int t = bx * 16 + rw * 4 + rt;
                 t = t < n_tiles ? t : n_tiles - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -641,7 +595,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[rt][j] = (WS ? facc[rt][tt][j] : combine_digits<NDIG>(&acc[rt][tt * NDIG], j)) * is;
-        store_wave_tiles(p, val, tok0, c, g, bx * (4 * RW) + rw * 4);
+        store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
     }
 }
 
@@ -650,13 +604,10 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void k_gemm_mfma(GemmArgs p) {
 // product, per-block scale" as north_star words it.  The int8 digit form above has to fold every 32-block's integer sums into f32
 // with that block's scale -- 3 VALU per (row, token, block), 768 of the 980 VALU instructions of a K step -- which
 // made the headline storage format prefill at HALF the QK256 rate.  Here the block scale is folded into the WEIGHT instead:
-// the A operand of v_mfma_f32_16x16x32_f16 is (+-s or 0) as f16 -- exact, s is an f16 value -- so one MFMA = one 32-block whose
-// result accumulates straight into the f32 accumulator of the whole K loop: no fold, no per-block epilogue, and one MFMA per
-// (block, row tile, token tile) instead of two digit MFMAs.  Activations are f16 with one power-of-two scale per row (row maximum
-// in [1, 2): 11-bit mantissa per ELEMENT, 2^-12 relative rounding each), staged [token][K] in LDS.
-//   expand: code bytes c -> selector bytes [0x0C, c_a, 0x0C, c_b] (v_perm_b32) -> f16 pair (t_a, t_b), t = code map value, through a
-//   LUT of the values' HIGH bytes (every value in {-2 .. 2} has a zero low byte) -> v_pk_mul_f16 by (s, s): 16 VALU per 8 weights.
-// Tile: 256 weight rows x 16 TTW tokens per 4-wave workgroup, two per CU, as the QK256 form.
+// the A operand of v_mfma_f32_16x16x32_f16 is (+-s or 0) as f16 -- exact, s is an f16 value -- accumulating straight into the f32
+// accumulator of the whole K loop: no fold, no per-block epilogue, and one MFMA per (32 columns, row tile, token tile) instead of two
+// digit MFMAs.  Activations are f16 with one power-of-two scale per row (row maximum in [1, 2): 11-bit mantissa per ELEMENT, 2^-12
+// relative rounding each).  Kernel: k_gemm_f16a below.
 
 // activation rows -> f16 planes [row][kp] (zero padded), inv_scale[row] = 2^E (0 for padding rows)
 template <int NV>
@@ -730,13 +681,41 @@ __global__ __launch_bounds__(256) void k_quant_rows_f16(QuantArgs p) {
 
 typedef _Float16 gh2 __attribute__((ext_vector_type(2)));
 typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
-typedef float gv4f __attribute__((ext_vector_type(4)));
-constexpr int kRowStrideH = 528;  // LDS bytes per token row of the f16 activation tile: 256 halves + 16 bytes
 
-template <int TTW>
-__global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_hi) {
-    constexpr int WG_TOK = TTW * 16;
-    constexpr int NB = WG_TOK * 32 / 256;  // 16-byte segments per thread per K step (32 per token row)
+// ================================================================================================================================
+// k_gemm_f16a: both storage formats on the f16 matrix cores.  Round 3's form (k_gemm_f16w) made one MFMA = one 32-block, for which each
+// wave dealt its four 1-KiB tiles through a private LDS area (4 ds_write_b128 + 32 ds_read_b32 per K step) and fetched four scale dwords
+// per row tile; this form needs neither -- measured, same box, 4096 tokens, quantiser included: gate|up 390 -> 366 us, down 236 -> 211,
+// o 94 -> 85, q|k|v 122 -> 113.  A lane (row r, group g)
+// of a streaming tile holds the 64 codes of columns 64 g .. 64 g + 63 of the 256-block (dword m = columns 16 m .. 16 m + 15 of them, the
+// sixteen 2-bit fields transposed 4 x 4: kernels_mfma.hip k_retile).  The K = 32 MFMA (m, h) takes from every lane the EIGHT codes of
+// columns 64 g + 16 m + 8 h .. + 7 -- its own registers, no exchange -- i.e. its 32 k-slots are four runs of 8 columns, one per lane
+// group; the B operand only has to agree: lane (token c, group g) reads the 8 halves of token c at column 64 g + 16 m + 8 h, one 16-byte
+// unit of the token's row.  The 32-element block of those columns is 2 g + (m >> 1): the lane's own k-group in the f16 scale tiles
+// ([tile][256-block][k-group][row][2]: ONE dword per row tile and K step instead of four).
+// Activation tile in LDS: [token 16 TTW][256 halves], unpadded, 16-byte unit u of token c stored at u ^ fswz(c), fswz(c) = (c & 3) |
+// ((c & 8) >> 1): with it the four 16-lane service groups of a ds_read_b128 each touch sixteen different units (brute-forced over the
+// lane groups of MI355X_MICROARCH.md's LDS table); double-buffered, one barrier per K step, the next step's loads in flight.
+// FMT 0: QK256 (code map values as f16, no scale); FMT 1: BitNet32-F16 (value x the block's f16 scale, v_pk_mul_f16).
+__device__ __forceinline__ int fswz(int c) { return (c & 3) | ((c & 8) >> 1); }
+
+template <int FMT>
+__device__ __forceinline__ gh8 expand8_f16(uint32_t w, int h, uint32_t lut_hi, gh2 s2) {
+    const uint32_t ca = (w >> (4 * h)) & 0x03030303u, cb = (w >> (4 * h + 2)) & 0x03030303u;
+    uint32_t t[4];
+    t[0] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x01040004u));
+    t[1] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x03040204u));
+    t[2] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x01040004u));
+    t[3] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x03040204u));
+    gh2 w2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w2[q] = FMT == 1 ? __builtin_bit_cast(gh2, t[q]) * s2 : __builtin_bit_cast(gh2, t[q]);
+    return (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
+}
+
+template <int FMT, int TTW>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_hi) {
+    constexpr int WG_TOK = TTW * 16, NB = WG_TOK * 32 / 256, ROWB = 512, kBuf = WG_TOK * ROWB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4, rw = wave;
@@ -752,13 +731,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
         }
     }
     const uint8_t *wptr[4];
-    const uint32_t *sptr[4];  // this lane's row of the f16 scale tiles: dword (kg, row c) = blocks 2 kg, 2 kg + 1
+    const uint32_t *sptr[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         int t = bx * 16 + rw * 4 + rt;
         t = t < n_tiles ? t : n_tiles - 1;
         wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
-        sptr[rt] = reinterpret_cast<const uint32_t *>(p.stiles_h) + (size_t)t * p.nblk * 64 + c;
+        sptr[rt] = FMT == 1 ? reinterpret_cast<const uint32_t *>(p.stiles_h) + (size_t)t * p.nblk * 64 + g * 16 + c : nullptr;
     }
     const _Float16 *planes = reinterpret_cast<const _Float16 *>(p.planes);
     const uint8_t *bsrc[NB];
@@ -767,85 +746,79 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16w(GemmArgs p, uint32_t lut_h
     for (int i = 0; i < NB; ++i) {
         const int idx = tid + 256 * i, tok = idx >> 5, seg = idx & 31;
         bsrc[i] = reinterpret_cast<const uint8_t *>(planes + (size_t)(by * WG_TOK + tok) * kp) + seg * 16;
-        bdst[i] = tok * kRowStrideH + seg * 16;
+        bdst[i] = tok * ROWB + (seg ^ fswz(tok & 15)) * 16;
     }
-    constexpr int kBuf = WG_TOK * kRowStrideH;
-    uint8_t *wst = lds + kBuf + wave * 4096;                // this wave's tile staging area (the K = 32 deal, as WS == 3)
-    const uint8_t *wrd = wst + c * 16 + 4 * (g >> 1);
-    const int sh3 = 4 * (g & 1);
-    const uint8_t *bread = lds + c * kRowStrideH + 16 * g;  // token c of a 16-token tile, this lane's 8 k of 32-block 0
+    int boff[8];  // this lane's unit of MFMA (m, h): 8 g + ((2 m + h) ^ fswz(c))
+#pragma unroll
+    for (int u = 0; u < 8; ++u) boff[u] = c * ROWB + 128 * g + ((u ^ fswz(c)) * 16);
     gv4f acc[4][TTW];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
     gv4u wn[4], bn[NB];
-    uint32_t sn[4][4];
+    uint32_t sn[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
+    if (FMT == 1) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) sn[rt] = sptr[rt][0];
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+    {
+        const int n1 = p.nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) sn[rt][kg] = sptr[rt][kg * 16];
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 512);
+    }
+    __syncthreads();
 
     for (int blk = 0; blk < p.nblk; ++blk) {
-        __syncthreads();  // the previous step's LDS reads are done
+        const uint8_t *bcur = lds + (blk & 1) * kBuf;
+        uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
+        if (blk + 1 < p.nblk) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
+        }
+        gv4u wc[4];
+        uint32_t sc[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<gv4u *>(wst + rt * 1024 + lane * 16) = wn[rt];
-        uint32_t sc[4][4];
+        for (int rt = 0; rt < 4; ++rt) wc[rt] = wn[rt], sc[rt] = sn[rt];
+        {
+            const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
+            if (FMT == 1) {
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) sc[rt][kg] = sn[rt][kg];
-        __syncthreads();
-        {  // the next step's loads are in flight during this step's MFMAs
-            const int nx = blk + 1 < p.nblk ? blk + 1 : blk;
+                for (int rt = 0; rt < 4; ++rt) sn[rt] = sptr[rt][(size_t)n1 * 64];
+            }
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)nx * 1024);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)nx * 512);
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) sn[rt][kg] = sptr[rt][(size_t)nx * 64 + kg * 16];
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 512);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // 64-column group i = 32-blocks 2 i, 2 i + 1 of this 256-block
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
+            for (int h = 0; h < 2; ++h) {
                 gh8 a[4];
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
-                    // eight 2-bit fields = this lane's 8 k of the block (the deal of WS == 3)
-                    const uint32_t wd = *reinterpret_cast<const uint32_t *>(wrd + rt * 1024 + i * 256 + 8 * hb) >> sh3;
-                    const uint32_t ca = wd & 0x03030303u, cb = (wd >> 2) & 0x03030303u;
-                    // (s, s) of block 2 i + hb
-                    const uint32_t ss = __builtin_amdgcn_perm(0u, sc[rt][i], hb ? 0x03020302u : 0x01000100u);
-                    const gh2 s2 = __builtin_bit_cast(gh2, ss);
-                    uint32_t t[4];
-                    t[0] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x01040004u));
-                    t[1] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, ca, 0x03040204u));
-                    t[2] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x01040004u));
-                    t[3] = __builtin_amdgcn_perm(0u, lut_hi, __builtin_amdgcn_perm(0x0C0C0C0Cu, cb, 0x03040204u));
-                    gh2 w2[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w2[q] = __builtin_bit_cast(gh2, t[q]) * s2;
-                    a[rt] = (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
+                    const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
+                    // (s, s) of this lane's 32-block 2 g + (m >> 1): low / high half of its scale dword
+                    const gh2 s2 = __builtin_bit_cast(gh2, __builtin_amdgcn_perm(0u, sc[rt], (m >> 1) ? 0x03020302u : 0x01000100u));
+                    a[rt] = expand8_f16<FMT>(wd, h, lut_hi, s2);
                 }
 #pragma unroll
                 for (int ct = 0; ct < TTW; ++ct) {
-                    const gh8 b = *reinterpret_cast<const gh8 *>(bread + ct * 16 * kRowStrideH + 128 * i + 64 * hb);
+                    const gh8 b = *reinterpret_cast<const gh8 *>(bcur + ct * 16 * ROWB + boff[2 * m + h]);
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();
     }
-    // ---- epilogue: x 2^E_t, [residual | silu * mul], store (k_gemm_mfma's) ------------------------------------------------------------
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
         const int tok0 = (by * TTW + tt) * 16;
@@ -867,7 +840,7 @@ thread_local GemmTileChoice g_last_gemm_tile;  // what the last launch on this t
 //      output rows are 160 such tiles for 512 slots): narrower tiles until it does;
 //  (b) its last round would leave most slots idle: 2560 output rows x 4096 tokens are 640 tiles on 512 slots -- two rounds for
 //      1.25 rounds of work.  32-token tiles run THREE to a CU (132 registers, 32 KiB of LDS): 1280 tiles on 768 slots.  Measured,
-//      same box: o 74 -> 68 us, down 173 -> 160 us (quantiser included).  int8 form only: k_gemm_f16w's 32-token form (its staging
+//      same box: o 74 -> 68 us, down 173 -> 160 us (quantiser included).  int8 form only: the f16 kernel's 32-token form (its staging
 //      and scale work per MFMA double) LOSES 2 % of the BitNet32-F16 prefill under the same rule.
 static int gemm_token_tiles(size_t gx0, size_t m_pad, bool tail_rule) {
     int ttw = 4;
@@ -907,7 +880,7 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
     constexpr int TT32 = NDIG <= 3 ? 2 : 1;  // 32-block scales: token tiles per wave that still fit the registers
     void (*gk)(GemmArgs) = k32 ? k_gemm_mfma<NDIG, TT32, 3> : !a.wscale ? k_gemm_mfma<NDIG, TTW, 0> : bs32 ? k_gemm_mfma<NDIG, TT32, 2> : k_gemm_mfma<NDIG, TTWS, 1>;
-    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS, cw = 2, rw = 4;
+    int ttw = (!a.wscale && !k32) ? TTW : bs32 ? TT32 : TTWS, cw = 2;
     const bool scaled_variant = a.wscale || k32;
     // 4-wave workgroups (256 rows x TTW token tiles) bounded to two waves per SIMD: two workgroups share a CU with independent
     // barriers (one stages its next tile while the other multiplies) at the full register budget, and a 2560-row matrix x
@@ -924,17 +897,6 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             ttw = gemm_token_tiles(gx0, q.m_pad, true);
             if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
             if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
-            // 512-row workgroups (8 waves, one workgroup per CU) where they still cover the chip twice over
-            static const int rw8_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_RW8"); return e ? atoi(e) : 0; }();
-            static const int var_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_VAR"); return e ? atoi(e) : 0; }();
-            if (rw8_mode && ttw == 4 && div_ceil(gx0, 2) * (q.m_pad / 64) >= 2 * kGemmCUs) {
-                gk = var_mode == 2 ? k_gemm_mfma<2, 4, 0, 1, 1, 8, 2> : var_mode == 1 ? k_gemm_mfma<2, 4, 0, 1, 1, 8, 1> : k_gemm_mfma<2, 4, 0, 1, 1, 8>;
-                rw = 8;
-            } else if (ttw == 4 && var_mode) {
-                gk = var_mode == 2 ? k_gemm_mfma<2, 4, 0, 2, 1, 4, 2> : k_gemm_mfma<2, 4, 0, 2, 1, 4, 1>;
-            } else if (ttw == 2 && var_mode) {
-                gk = var_mode == 2 ? k_gemm_mfma<2, 2, 0, 2, 1, 4, 2> : k_gemm_mfma<2, 2, 0, 2, 1, 4, 1>;
-            }
         }
     }
     const size_t lds = (size_t)cw * NDIG * ttw * 16 * (k32 ? kColStride : 256) * (scaled_variant ? 1 : 2) + (k32 ? (size_t)4 * cw * 4096 : 0);  // unscaled: double-buffered; K = 32: + tile staging
@@ -949,13 +911,13 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             raised.insert((const void *)gk);
         }
     }
-    g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, rw * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
-    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 4 * (size_t)rw), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
-    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(64 * rw * cw), lds, stream, a);
+    g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, 4 * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
+    const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
+    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, a);
     return hipGetLastError();
 }
 
-// k_gemm_f16w builds (code value) x (block scale) in f16: only code maps whose four values are in -2 .. 2 (every map of the
+// k_gemm_f16a builds (code value) x (block scale) in f16: only code maps whose four values are in -2 .. 2 (every map of the
 // reference: their f16 images have a zero low byte, lut_f16_hi) and scales whose double is finite in f16 take it; any other
 // matrix (bitnet_hip_weights_upload_coded accepts an arbitrary int8 code map) keeps the exact int8 digit form.
 static bool lut_fits_f16w(uint32_t lut) {
@@ -976,17 +938,30 @@ static uint32_t lut_f16_hi(uint32_t lut) {
     return out;
 }
 
-static hipError_t launch_gemm_f16w(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
+// f16 activations on the f16 matrix cores (k_gemm_f16a): BitNet32-F16 at 2 digits; QK256 only on request (BITNET_HIP_GEMM_F16A=1:
+// measured 5-13 % slower than the int8 digit form there -- twice the expansion VALU for the same MFMA count)
+static hipError_t launch_gemm_f16(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
     const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows_f16<3> : k_quant_rows_f16<8>;
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     // token tile: 64 (TTW 4) while the grid still covers the chip twice over, else narrower (short prompts, one rank's share)
     const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
     const int ttw = gemm_token_tiles(gx0, q.m_pad, false);
-    void (*gk)(GemmArgs, uint32_t) = ttw == 4 ? k_gemm_f16w<4> : ttw == 2 ? k_gemm_f16w<2> : k_gemm_f16w<1>;
-    const size_t lds = (size_t)ttw * 16 * kRowStrideH + 4 * 4096;
-    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 4};
-    hipLaunchKernelGGL(gk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
+    const bool fmt1 = a.stiles_h != nullptr;
+    void (*fk)(GemmArgs, uint32_t) = fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4> : ttw == 2 ? k_gemm_f16a<1, 2> : k_gemm_f16a<1, 1>)
+                                          : (ttw == 4 ? k_gemm_f16a<0, 4> : ttw == 2 ? k_gemm_f16a<0, 2> : k_gemm_f16a<0, 1>);
+    {
+        static std::mutex f_mu;
+        static std::unordered_set<const void *> f_raised;
+        std::lock_guard<std::mutex> lk(f_mu);
+        if (!f_raised.count((const void *)fk)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            f_raised.insert((const void *)fk);
+        }
+    }
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5};
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 512, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
 }
 
@@ -1024,7 +999,12 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
-    if (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite) return launch_gemm_f16w(w, q, a, stream);  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
+    if (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite) return launch_gemm_f16(w, q, a, stream);
+    {
+        static const int f16a_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16A"); return e ? atoi(e) : 0; }();
+        if (f16a_mode && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 256 == 0)
+            return launch_gemm_f16(w, q, a, stream);
+    }  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
     return launch_gemm_t<4, 2>(w, q, a, stream);

@@ -4,7 +4,9 @@
 mkdir -p gpurun_out
 out=gpurun_out/ab_gemm.log
 : > $out
-for data in random zeros zero_x const_w; do
-  echo "== data $data" | tee -a $out
-  python3 tools/perf_gemm.py --digits 2 --reps 30 --data $data --shapes gate_up down 2>&1 | grep -v amdgpu.ids | tee -a $out
+for fmt in qk256 i2s; do
+for cfg in "F16A=0" "F16A=1" "F16A=0" "F16A=1"; do
+  echo "== $fmt $cfg" | tee -a $out
+  env BITNET_HIP_GEMM_${cfg} python3 tools/perf_gemm.py --fmt $fmt --digits 2 --check --reps 30 2>&1 | grep -v amdgpu.ids | tee -a $out
+done
 done

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--digits", type=int, nargs="+", default=[4, 3, 2])
     ap.add_argument("--shapes", nargs="+", default=["qkv", "o", "gate_up", "down"])
     ap.add_argument("--data", default="random", choices=["random", "zero_x", "const_w", "zeros"], help="operand data (DVFS check: the chip holds a higher clock on trivial operands)")
+    ap.add_argument("--fmt", default="qk256", choices=["qk256", "i2s"], help="storage format: QK256 (no scales) or BitNet32-F16 (ternary, f16 scale per 32)")
     ap.add_argument("--check", action="store_true", help="compare each result with the 4-digit one (cosine, max abs / max)")
     args = ap.parse_args()
     hip = pkg.load()
@@ -36,7 +37,12 @@ def main():
         qs = rng.integers(0, 256, n * stride, dtype=np.uint8)
         if args.data in ("const_w", "zeros"):
             qs[:] = 0xAA
-        h = hip.weights_upload_qk256(qs, n, k, stride)
+        if args.fmt == "i2s":
+            synth = importlib.import_module("bitnet-rs_amd.synth")
+            wq, ws_ = synth.ternary_weights(n, k, 32, 42, 0, 1)
+            h = hip.weights_upload_i2s(wq, ws_, n, k, 32)
+        else:
+            h = hip.weights_upload_qk256(qs, n, k, stride)
         x = torch.randn(m, k, device="cuda")
         if args.data in ("zero_x", "zeros"):
             x.zero_()
