@@ -325,6 +325,27 @@ class HipLib:
                                                        _ptr(residual) if residual is not None else None, flags, digits, _ptr(workspace),
                                                        workspace_bytes, _vp(stream)))
 
+    # -- the prompt forward's f16 activation chain (include/bitnet_hip.h) --------------------------------------------------------
+    def matmul_f16_supported(self, h: int) -> bool:
+        self.c.bitnet_hip_matmul_f16_supported.argtypes = [C.c_uint64]
+        return bool(self.c.bitnet_hip_matmul_f16_supported(h))
+
+    def rows_to_f16_dev(self, x, gamma, m: int, cols: int, xh, stats, stream: int = 0) -> None:
+        self.c.bitnet_hip_rows_to_f16_dev.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp, _vp]
+        self._check(self.c.bitnet_hip_rows_to_f16_dev(_ptr(x), _optr(gamma), m, cols, _ptr(xh), _optr(stats), _vp(stream)))
+
+    def matmul_f16_dev(self, h: int, xh, m: int, stats_in=None, n_stats: int = 0, ln_gamma=None, ln_eps: float = 0.0, y=None, residual=None,
+                       flags: int = 0, yh=None, gamma_out=None, stats_out=None, stream: int = 0) -> None:
+        self.c.bitnet_hip_matmul_f16_dev.argtypes = [C.c_uint64, _vp, _sz, _vp, _sz, _vp, C.c_float, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
+        self._check(self.c.bitnet_hip_matmul_f16_dev(h, _ptr(xh), m, _optr(stats_in), n_stats, _optr(ln_gamma), ln_eps, _optr(y), _optr(residual), flags,
+                                                     _optr(yh), _optr(gamma_out), _optr(stats_out), _vp(stream)))
+
+    def attention_prefill_flags_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, seq_len, workspace, workspace_bytes,
+                                    out, flags: int, stream: int = 0) -> None:
+        self.c.bitnet_hip_attention_prefill_flags_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, C.c_int, _vp]
+        self._check(self.c.bitnet_hip_attention_prefill_flags_dev(_ptr(qkv), _ptr(rope_sin), _ptr(rope_cos), _ptr(kcache), _ptr(vcache), n_heads, n_kv,
+                                                                  head_dim, max_pos, seq_len, _ptr(workspace), workspace_bytes, _ptr(out), flags, _vp(stream)))
+
     def matmul_last_tile(self) -> dict:
         """The tile form this thread's last tiled matmul ran: {digits, wave_tokens, waves, scale_mode}."""
         v = [C.c_int() for _ in range(4)]

@@ -512,6 +512,52 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     BH_GUARD_END
 }
 
+int bitnet_hip_matmul_f16_supported(bitnet_hip_weights_t h) {
+    const WeightsRef w = lookup(h);
+    return w && gemm_f16_chain_supported(*w) ? 1 : 0;
+}
+
+int bitnet_hip_rows_to_f16_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *xh_dev, float *stats_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!x_dev || !xh_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to rows_to_f16_dev");
+    if (m == 0 || cols == 0 || cols % 4 != 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "rows_to_f16_dev: m > 0 and cols %% 4 == 0 expected: m=%zu, cols=%zu", m, cols);
+    hipError_t e = launch_rows_to_f16(x_dev, gamma_dev, m, cols, xh_dev, stats_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t h, const void *xh_dev, size_t m, const float *stats_in_dev, size_t n_stats,
+                              const float *ln_gamma_dev, float ln_eps, float *y_dev, const float *residual_dev, int flags, void *yh_dev,
+                              const float *gamma_out_dev, float *stats_out_dev, void *stream) {
+    BH_GUARD_BEGIN
+    const WeightsRef w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!xh_dev || (!y_dev && !yh_dev)) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_f16_dev");
+    if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    if (!gemm_f16_chain_supported(*w))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "matmul_f16_dev: this matrix does not take the f16 chain (rows %% 256, cols %% 256, code map in -2..2, f16 block scales)");
+    if ((ln_gamma_dev != nullptr) != (stats_in_dev != nullptr) || (ln_gamma_dev && (!w->ln_g || w->ln_gamma_bound != ln_gamma_dev || n_stats == 0)))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "matmul_f16_dev: LayerNorm needs the bound gamma (bitnet_hip_weights_bind_ln) and its statistics partials");
+    GemmF16Io io;
+    io.xh = xh_dev;
+    io.stats_in = stats_in_dev;
+    io.n_stats = (int)n_stats;
+    io.ln_eps = ln_eps;
+    io.y = y_dev;
+    io.residual = residual_dev;
+    io.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    io.yh = yh_dev;
+    io.gamma_out = gamma_out_dev;
+    io.stats_out = stats_out_dev;
+    if (io.silu_mul && (!w->paired || residual_dev))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    hipError_t e = launch_gemm_f16_chain(*w, io, m, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
 int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode) {
     const GemmTileChoice &t = g_last_gemm_tile;
     if (digits) *digits = t.digits;
@@ -1034,6 +1080,24 @@ int bitnet_hip_attention_prefill_kv16_dev(const float *qkv, const float *rope_si
     BH_HIP_TRY(launch_attn_prefill(qkv, ld, nullptr, (int)seq_len, qkv + n_heads * head_dim, ld, (int)seq_len, rope_sin, rope_cos, static_cast<float *>(kcache_f16),
                                    static_cast<float *>(vcache_f16), (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes, out,
                                    (hipStream_t)stream, 0, 0, 1));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_attention_prefill_flags_dev(const float *qkv, const float *rope_sin, const float *rope_cos, void *kcache, void *vcache, size_t n_heads,
+                                           size_t n_kv_heads, size_t head_dim, size_t max_pos, size_t seq_len, void *workspace, size_t workspace_bytes,
+                                           void *out, int flags, void *stream) {
+    BH_GUARD_BEGIN
+    int rc = check_prefill_args(qkv, qkv, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, seq_len);
+    if (rc) return rc;
+    if (flags & ~(BITNET_HIP_ATTN_CACHE_F16 | BITNET_HIP_ATTN_OUT_F16)) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_flags_dev: unknown flag bits 0x%x", flags);
+    const size_t need = attn_prefill_workspace_bytes((int)n_heads, (int)n_kv_heads, (int)seq_len, (int)seq_len);
+    if (workspace_bytes < need)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
+    const int ld = (int)((n_heads + 2 * n_kv_heads) * head_dim);
+    BH_HIP_TRY(launch_attn_prefill(qkv, ld, nullptr, (int)seq_len, qkv + n_heads * head_dim, ld, (int)seq_len, rope_sin, rope_cos, static_cast<float *>(kcache),
+                                   static_cast<float *>(vcache), (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)max_pos, workspace, workspace_bytes,
+                                   static_cast<float *>(out), (hipStream_t)stream, 0, 0, flags));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }

@@ -166,6 +166,25 @@ size_t weights_device_bytes(const Weights &w);
 bool gemm_supported(const Weights &w);
 bool gemm_needs_row_major_scales(const Weights &w);  // 256-block scales and non-f16 32-block scales: the others read the scale tiles
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);
+// The f16 activation chain of the prompt forward (kernels_gemm.hip k_gemm_f16a<.., 1>): the input is an f16 matrix [m_pad][cols]
+// (m_pad = m rounded up to 64 rows) written by the kernel that PRODUCED the activations; LayerNorm of the input is applied after the
+// product from per-slab (sum, sum of squares) partials of the exact f32 rows (needs bitnet_hip_weights_bind_ln); outputs: f32 rows
+// (optionally residual + W x), and / or f16 rows (optionally x gamma_out: the next LayerNorm's weight) + the next partials.
+struct GemmF16Io {
+    const void *xh = nullptr;
+    const float *stats_in = nullptr;  // float2 [n_stats][m_pad]
+    int n_stats = 0;
+    float ln_eps = 0.0f;
+    float *y = nullptr;               // f32 [m][rows] (rows / 2 with silu_mul), nullable
+    const float *residual = nullptr;  // f32 [m][rows], may alias y
+    bool silu_mul = false;
+    void *yh = nullptr;               // f16 [m_pad][rows] (rows / 2 with silu_mul), nullable
+    const float *gamma_out = nullptr; // [rows]: yh = f16(gamma_out * y)
+    float *stats_out = nullptr;       // float2 [rows / 64][m_pad]
+};
+bool gemm_f16_chain_supported(const Weights &w);
+hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream);
+hipError_t launch_rows_to_f16(const float *x, const float *gamma, size_t m, size_t cols, void *xh, float *stats, hipStream_t stream);
 hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
                             void *workspace, size_t workspace_bytes, hipStream_t stream);
 // the tile form launch_gemm_mfma chose on this thread's last call: digits, tokens per wave tile (16 x TTW), waves per workgroup,

@@ -50,6 +50,15 @@ struct GemmArgs {
     const float *wscale;    // optional f32 per (row, 256-block) / (row, 32-block), row-major
     const uint16_t *stiles_h;  // WS == 3: f16 32-block scale tiles [tile][blk][kg][row][p] (k_retile_scales_h)
     int silu_mul;
+    // ---- the f16 activation chain (k_gemm_f16a<.., EPI = 1>): `planes` = raw f16 rows [m_pad][cols] written by the PRODUCER of the
+    // activations (inv_scale null), LayerNorm applied after the product, outputs handed on as f16 ----------------------------------
+    const float *stats_in = nullptr;  // LayerNorm of the input: (sum, sum of squares) partials [n_stats][stats_stride] float2 over its columns
+    int n_stats = 0, stats_stride = 0;
+    float ln_eps = 0.0f;
+    const float *ln_g = nullptr;       // g_r = W[r, :] . gamma (bitnet_hip_weights_bind_ln)
+    _Float16 *yh = nullptr;            // f16 output rows [m_pad][rows] ([m_pad][rows / 2] with silu_mul), optionally x gamma_out[row]
+    const float *gamma_out = nullptr;
+    float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
 };
 
 struct QuantArgs {
@@ -713,7 +722,7 @@ __device__ __forceinline__ gh8 expand8_f16(uint32_t w, int h, uint32_t lut_hi, g
     return (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
 }
 
-template <int FMT, int TTW>
+template <int FMT, int TTW, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_hi) {
     constexpr int WG_TOK = TTW * 16, NB = WG_TOK * 32 / 256, ROWB = 512, kBuf = WG_TOK * ROWB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -819,16 +828,150 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         __syncthreads();
     }
+    if (EPI == 0) {
+#pragma unroll
+        for (int tt = 0; tt < TTW; ++tt) {
+            const int tok0 = (by * TTW + tt) * 16;
+            const float is = p.inv_scale[tok0 + c];
+            float val[4][4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
+            store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
+        }
+        return;
+    }
+    // ---- the f16 chain's epilogues -------------------------------------------------------------------------------------------------
+    // LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma;
+    // mean / denom from the producer's per-slab partial sums of the exact f32 x, added up here in a fixed order (f64): deterministic
+    float2 *mu_rs = reinterpret_cast<float2 *>(lds);  // (the K loop's last barrier is behind every wave: the tile buffers are free)
+    if (p.stats_in) {
+        constexpr int NG = 256 / WG_TOK;
+        double *red = reinterpret_cast<double *>(lds + 1024);
+        const int tk = tid % WG_TOK, pg = tid / WG_TOK;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = pg; i < p.n_stats; i += NG) {
+            const float2 v = *reinterpret_cast<const float2 *>(p.stats_in + 2 * ((size_t)i * p.stats_stride + by * WG_TOK + tk));
+            s1 += (double)v.x, s2 += (double)v.y;
+        }
+        red[2 * tid] = s1, red[2 * tid + 1] = s2;
+        __syncthreads();
+        if (tid < WG_TOK) {
+            s1 = s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) s1 += red[2 * (q * WG_TOK + tid)], s2 += red[2 * (q * WG_TOK + tid) + 1];
+            const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
+            const float denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+            mu_rs[tid] = float2{(float)mean_d, 1.0f / denom};
+        }
+        __syncthreads();
+    }
+    const int tile0 = bx * 16 + rw * 4;
+    float lng[4][4], gout[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        int row0 = 16 * (tile0 + rt) + 4 * g;
+        row0 = row0 + 3 < p.rows ? row0 : p.rows - 4;  // (rows % 256 == 0 on this path: never taken)
+        const float4 lg = p.stats_in ? *reinterpret_cast<const float4 *>(p.ln_g + row0) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 go = p.gamma_out ? *reinterpret_cast<const float4 *>(p.gamma_out + row0) : float4{1.f, 1.f, 1.f, 1.f};
+        lng[rt][0] = lg.x, lng[rt][1] = lg.y, lng[rt][2] = lg.z, lng[rt][3] = lg.w;
+        gout[rt][0] = go.x, gout[rt][1] = go.y, gout[rt][2] = go.z, gout[rt][3] = go.w;
+    }
+    typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
-        const int tok0 = (by * TTW + tt) * 16;
-        const float is = p.inv_scale[tok0 + c];
+        const int tok0 = (by * TTW + tt) * 16, token = tok0 + c;
+        const bool live = token < p.m;
         float val[4][4];
+        float2 mr = float2{0.f, 1.f};
+        if (p.stats_in) mr = mu_rs[tt * 16 + c];
+        const float is = p.inv_scale ? p.inv_scale[token] : 1.0f;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
-        store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
+            for (int j = 0; j < 4; ++j) val[rt][j] = (acc[rt][tt][j] * is - mr.x * lng[rt][j]) * mr.y;
+        if (p.silu_mul) {
+            // row tiles alternate (gate, up): FeedForward::forward T:756-781; the product goes out as f16 rows for the down-projection
+            const int half_rows = p.rows >> 1, ra = 16 * (tile0 >> 1) + 4 * g;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
+                    r[j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+                if (live) {
+                    if (p.yh) {
+                        gh4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[j], -65504.0f, 65504.0f);
+                        *reinterpret_cast<gh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
+                    }
+                    if (p.y) store_out4(p.y + (size_t)token * half_rows + ra + 16 * pr, r[0], r[1], r[2], r[3]);
+                }
+            }
+            continue;
+        }
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row0 = 16 * (tile0 + rt) + 4 * g;
+            const size_t off = (size_t)(live ? token : 0) * p.rows + row0;
+            if (p.residual) {  // x = x + W h (in place: y aliases the residual), T:1073
+                const float4 rv = *reinterpret_cast<const float4 *>(p.residual + off);
+                val[rt][0] += rv.x, val[rt][1] += rv.y, val[rt][2] += rv.z, val[rt][3] += rv.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += val[rt][j], s2 += val[rt][j] * val[rt][j];
+            if (live) {
+                if (p.y) *reinterpret_cast<float4 *>(p.y + off) = float4{val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
+                if (p.yh) {
+                    gh4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(val[rt][j] * gout[rt][j], -65504.0f, 65504.0f);
+                    *reinterpret_cast<gh4 *>(p.yh + off) = o;
+                }
+            }
+        }
+        if (p.stats_out) {  // this wave's 64 rows of the token: the consumer's LayerNorm adds the slabs up
+            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+            if (g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(bx * 4 + rw) * p.stats_stride + token)) = live ? float2{s1, s2} : float2{0.f, 0.f};
+        }
+    }
+}
+
+// f32 rows -> the f16 chain's first input: xh = f16(gamma * x) (nullable gamma: 1) and the row's (sum, sum of squares) as partial 0
+// of the consumer's LayerNorm statistics.  One workgroup per row; used once per prompt (the embedding rows); every later hand-over is
+// an epilogue of the kernel that produced the rows.
+__global__ __launch_bounds__(256) void k_rows_to_f16(const float *__restrict__ x, const float *__restrict__ gamma, int m, int m_pad, int cols,
+                                                     _Float16 *__restrict__ xh, float *__restrict__ stats, int stats_stride) {
+    __shared__ double red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool live = row < m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < cols / 4; i += 256) {
+        float4 v = live ? *reinterpret_cast<const float4 *>(x + (size_t)row * cols + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        if (gamma) {
+            const float4 gm = *reinterpret_cast<const float4 *>(gamma + 4 * i);
+            v.x *= gm.x, v.y *= gm.y, v.z *= gm.z, v.w *= gm.w;
+        }
+        typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+        const gh4 o = {(_Float16)__builtin_amdgcn_fmed3f(v.x, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(v.y, -65504.0f, 65504.0f),
+                       (_Float16)__builtin_amdgcn_fmed3f(v.z, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(v.w, -65504.0f, 65504.0f)};
+        *reinterpret_cast<gh4 *>(xh + (size_t)row * cols + 4 * i) = o;
+    }
+    s1 = qwave_sum_d(s1), s2 = qwave_sum_d(s2);
+    if (lane == 0) red[2 * wave] = s1, red[2 * wave + 1] = s2;
+    __syncthreads();
+    if (tid == 0 && stats) {
+        s1 = (red[0] + red[2]) + (red[4] + red[6]);
+        s2 = (red[1] + red[3]) + (red[5] + red[7]);
+        *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{(float)s1, (float)s2};
     }
 }
 
@@ -962,6 +1105,70 @@ static hipError_t launch_gemm_f16(const Weights &w, const QuantArgs &q, const Ge
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5};
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 512, stream, a, lut_f16_hi(w.lut));
+    return hipGetLastError();
+}
+
+// ---- the f16 activation chain: every projection input is an f16 matrix its PRODUCER wrote (no quantiser kernel between the launches) ----
+bool gemm_f16_chain_supported(const Weights &w) {
+    if (!w.tiles || w.cols % 256 != 0 || w.rows % 256 != 0 || w.cols > 8192) return false;
+    if (w.row_stride_bytes != div_ceil(w.cols, 256) * 64 || !lut_fits_f16w(w.lut)) return false;
+    if (w.scaled) return gemm_k32(w) && w.scales_f16_x2_finite;
+    return true;
+}
+
+hipError_t launch_rows_to_f16(const float *x, const float *gamma, size_t m, size_t cols, void *xh, float *stats, hipStream_t stream) {
+    if (cols % 4 != 0 || m == 0) return hipErrorInvalidValue;
+    const size_t m_pad = div_ceil(m, 64) * 64;
+    hipLaunchKernelGGL(k_rows_to_f16, dim3((unsigned)m_pad), dim3(256), 0, stream, x, gamma, (int)m, (int)m_pad, (int)cols, static_cast<_Float16 *>(xh), stats,
+                       (int)m_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream) {
+    if (!gemm_f16_chain_supported(w) || m == 0 || !io.xh) return hipErrorInvalidValue;
+    if (io.stats_in && !(w.ln_g && io.n_stats > 0)) return hipErrorInvalidValue;
+    if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
+    const size_t m_pad = div_ceil(m, 64) * 64;
+    GemmArgs a;
+    a.tiles = w.tiles;
+    a.stiles_h = w.scaled ? w.scale_tiles_h : nullptr;
+    a.rows = (int)w.rows;
+    a.cols = (int)w.cols;
+    a.nblk = (int)(w.cols / 256);
+    a.lut = w.lut;
+    a.planes = static_cast<const int8_t *>(io.xh);
+    a.inv_scale = nullptr;
+    a.y = io.y;
+    a.m = (int)m;
+    a.residual = io.residual;
+    a.wscale = nullptr;
+    a.silu_mul = io.silu_mul ? 1 : 0;
+    a.stats_in = io.stats_in;
+    a.n_stats = io.n_stats;
+    a.stats_stride = (int)m_pad;
+    a.ln_eps = io.ln_eps;
+    a.ln_g = w.ln_g;
+    a.yh = static_cast<_Float16 *>(io.yh);
+    a.gamma_out = io.gamma_out;
+    a.stats_out = io.stats_out;
+    const size_t gx0 = w.rows / 256;
+    const int ttw = gemm_token_tiles(gx0, m_pad, false);
+    const bool fmt1 = w.scaled;
+    void (*fk)(GemmArgs, uint32_t) = fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4, 1> : ttw == 2 ? k_gemm_f16a<1, 2, 1> : k_gemm_f16a<1, 1, 1>)
+                                          : (ttw == 4 ? k_gemm_f16a<0, 4, 1> : ttw == 2 ? k_gemm_f16a<0, 2, 1> : k_gemm_f16a<0, 1, 1>);
+    {
+        static std::mutex f_mu;
+        static std::unordered_set<const void *> f_raised;
+        std::lock_guard<std::mutex> lk(f_mu);
+        if (!f_raised.count((const void *)fk)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            f_raised.insert((const void *)fk);
+        }
+    }
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5};
+    const size_t lds = (size_t)2 * ttw * 16 * 512;  // (the epilogue's 5 KiB of statistics scratch fit the smallest tile pair: 16 KiB)
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ struct PrefillArgs {
     int zz_world, zz_chunk;  // ranks, tokens per chunk (T = 2 * world * chunk; chunk % 64 == 0)
     int kv_f16;              // the k|v rows travelled as f16 (half the bytes on the wire); k / v then point at _Float16
     int cache_f16;           // the decode caches hold f16 (kernels_attn.hip KV16 layout)
+    int out_f16;             // `out` holds _Float16 (same element strides): the o-projection's f16 chain reads it as it is (kernels_gemm.hip k_gemm_f16a)
     // key split: the key tiles of a query block are dealt to `ksplit` workgroups (blockIdx.z), each leaving an un-normalised partial
     // (o, m, l) that k_prefill_merge combines -- for launches whose query blocks alone would not fill the chip (one rank's 1024
     // queries x 8192 keys of the 8-GPU prefill are 160 workgroups with up to 128 key tiles each; a 1024-token prompt likewise)
@@ -513,11 +514,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         }
         if (qrow < p.nq) {
             const float inv = 1.0f / l;
-            float *op = p.out + (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
+            const size_t oo = (size_t)qrow * p.out_ld + (size_t)h * p.out_hs + 4 * g;
+            if (p.out_f16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                _Float16 *oh = reinterpret_cast<_Float16 *>(p.out) + oo;
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const float4 v = {o[q][dt][0] * inv, o[q][dt][1] * inv, o[q][dt][2] * inv, o[q][dt][3] * inv};
-                *reinterpret_cast<float4 *>(op + 16 * dt) = v;
+                for (int dt = 0; dt < 8; ++dt)
+                    *reinterpret_cast<h4 *>(oh + 16 * dt) = (h4){(_Float16)(o[q][dt][0] * inv), (_Float16)(o[q][dt][1] * inv), (_Float16)(o[q][dt][2] * inv), (_Float16)(o[q][dt][3] * inv)};
+            } else {
+                float *op = p.out + oo;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const float4 v = {o[q][dt][0] * inv, o[q][dt][1] * inv, o[q][dt][2] * inv, o[q][dt][3] * inv};
+                    *reinterpret_cast<float4 *>(op + 16 * dt) = v;
+                }
             }
         }
     }
@@ -544,6 +554,11 @@ __global__ __launch_bounds__(256) void k_prefill_merge(PrefillArgs p) {
         a.x += w * o.x, a.y += w * o.y, a.z += w * o.z, a.w += w * o.w;
     }
     const float inv = 1.0f / L;
+    if (p.out_f16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(p.out) + row * p.out_ld + h * p.out_hs + 4 * d4) = (h4){(_Float16)(a.x * inv), (_Float16)(a.y * inv), (_Float16)(a.z * inv), (_Float16)(a.w * inv)};
+        return;
+    }
     *reinterpret_cast<float4 *>(p.out + row * p.out_ld + h * p.out_hs + 4 * d4) = float4{a.x * inv, a.y * inv, a.z * inv, a.w * inv};
 }
 
@@ -617,7 +632,8 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.zz_world = zz_world;
     p.zz_chunk = zz_world > 0 ? T / (2 * zz_world) : 0;
     p.kv_f16 = kv_f16;
-    p.cache_f16 = cache_f16;
+    p.cache_f16 = cache_f16 & 1;
+    p.out_f16 = (cache_f16 >> 1) & 1;  // bit 1 of the flag word: f16 output rows
     p.ld_q = ld_q;
     p.ld_kv = ld_kv;
     p.hs_q = p.hs_kv = kPD;
@@ -693,7 +709,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.causal = causal;
     p.scale = scale;
     p.q_block_pos = nullptr;
-    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = p.phase = 0;
+    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = p.out_f16 = p.phase = 0;
     p.nq = seq;
     p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;

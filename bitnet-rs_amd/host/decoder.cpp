@@ -86,6 +86,7 @@ Decoder::Decoder(const Config &cfg) : c_(cfg), layers_(cfg.n_layers > 0 && cfg.n
     if (const char *e = getenv("BITNET_TRACE_DIR")) trace_dir_ = e;  // the reference's switch (crates/bitnet-trace/src/lib.rs:113-117)
     if (const char *e = getenv("BITNET_HOST_KV16")) kv_f16_ = atoi(e) != 0;  // opt-in f16 KV cache (long contexts)
     if (const char *e = getenv("BITNET_HOST_ACT")) act_mode_ = atoi(e) != 0 ? 1 : 0;  // 0: exact f32 activations between the kernels
+    if (const char *e = getenv("BITNET_HOST_PREFILL_CHAIN")) prefill_chain_ = atoi(e) != 0 ? 1 : 0;  // the prompt forward's f16 activation chain
     if (bitnet_hip_init(-1) != 0) {
         const char *e = bitnet_hip_get_last_error();
         err_ = e ? e : "bitnet_hip_init failed";
@@ -175,7 +176,7 @@ Decoder::~Decoder() {
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_, sp_kv_send_, sp_kv_all_,
-                    (void *)sp_block_pos_, (void *)sp_tokens_})
+                    (void *)sp_block_pos_, (void *)sp_tokens_, pf_xh_, pf_atth_, pf_hh_, (void *)pf_stats_})
         if (p) hipFree(p);
     for (void *e : sp_tev_)
         if (e) hipEventDestroy((hipEvent_t)e);
@@ -716,6 +717,66 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
     return 0;
 }
 
+// The prompt forward as an f16 ACTIVATION CHAIN (bitnet_hip_matmul_f16_dev): every projection reads f16 rows that the kernel producing
+// them wrote -- the o- / down-projection's epilogue leaves x (f32, the residual stream), f16(gamma_next * x) and the LayerNorm statistics
+// partials; the attention writes f16 rows; gate|up's epilogue writes f16(silu(gate) * up) -- so no row quantiser / conversion launch sits
+// between two matmuls (four per layer otherwise: 69 us of a 925 us BitNet32-F16 layer at 4096 tokens, and the f32 round trips they read).
+// Taken at digits = 2 (the f16-activation precision class) when every projection of the model takes the chain; automatic for the
+// block-scaled format, whose matmul runs on f16 activations anyway; BITNET_HOST_PREFILL_CHAIN=1 forces it for QK256 (whose int8 digit
+// matmul is the faster kernel: the default there stays the digit planes), =0 switches it off.
+bool Decoder::chain_applies(int digits) const {
+    if (digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
+    bool scaled_all = true;
+    for (const auto &L : layers_) {
+        for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down})
+            if (!h || !bitnet_hip_matmul_f16_supported(h)) return false;
+        size_t rows = 0, cols = 0, ab = 0;
+        if (bitnet_hip_weights_info(L.qkv, &rows, &cols, &ab) != 0) return false;
+        scaled_all = scaled_all && ab > rows * cols / 4;  // algorithmic bytes beyond the 2-bit codes: block scales
+    }
+    return prefill_chain_ == 1 || scaled_all;
+}
+
+int Decoder::prefill_chain_layers(size_t N) {
+    const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, F = c_.ffn;
+    const size_t NP = (N + 63) / 64 * 64, nst = H / 64;
+    hipStream_t s = (hipStream_t)stream_;
+    if ((int)NP > pfc_cap_) {
+        for (void *q : {pf_xh_, pf_atth_, pf_hh_, (void *)pf_stats_})
+            if (q) hipFree(q);
+        pf_xh_ = pf_atth_ = pf_hh_ = nullptr;
+        pf_stats_ = nullptr;
+        pfc_cap_ = 0;
+        HCHK(hipMalloc(&pf_xh_, NP * H * 2));
+        HCHK(hipMalloc(&pf_atth_, NP * QD * 2));
+        HCHK(hipMalloc(&pf_hh_, NP * F * 2));
+        HCHK(hipMalloc((void **)&pf_stats_, nst * NP * 2 * sizeof(float)));
+        // rows past the prompt are read by the last token tile (never stored): they must hold finite values
+        HCHK(hipMemsetAsync(pf_xh_, 0, NP * H * 2, s));
+        HCHK(hipMemsetAsync(pf_atth_, 0, NP * QD * 2, s));
+        HCHK(hipMemsetAsync(pf_hh_, 0, NP * F * 2, s));
+        HCHK(hipMemsetAsync(pf_stats_, 0, nst * NP * 2 * sizeof(float), s));
+        pfc_cap_ = (int)NP;
+    }
+    BCHK(bitnet_hip_rows_to_f16_dev(pf_x_, layers_[0].attn_norm, N, H, pf_xh_, pf_stats_, s));
+    size_t n_stats = 1;
+    const int aflags = (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | BITNET_HIP_ATTN_OUT_F16;
+    for (size_t l = 0; l < layers_.size(); ++l) {
+        auto &L = layers_[l];
+        BCHK(bitnet_hip_matmul_f16_dev(L.qkv, pf_xh_, N, pf_stats_, n_stats, L.attn_norm, c_.eps, pf_qkv_, nullptr, 0, nullptr, nullptr, nullptr, s));
+        BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                                    (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_atth_, aflags, s));
+        BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, pf_xh_, L.ffn_norm, pf_stats_, s));
+        n_stats = nst;
+        BCHK(bitnet_hip_matmul_f16_dev(L.gateup, pf_xh_, N, pf_stats_, n_stats, L.ffn_norm, c_.eps, nullptr, nullptr, BITNET_HIP_FUSE_SILU_MUL, pf_hh_, nullptr,
+                                       nullptr, s));
+        const bool last = l + 1 == layers_.size();
+        BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, last ? nullptr : pf_xh_,
+                                       last ? nullptr : layers_[l + 1].attn_norm, last ? nullptr : pf_stats_, s));
+    }
+    return 0;
+}
+
 int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     if (!embed_) {
         err_ = "model globals not set";
@@ -762,7 +823,13 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     HCHK(hipEventRecord(e0, s));
     const size_t N = (size_t)n;
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, N, H, (size_t)c_.vocab, pf_x_, s));  // *pos_ == 0
+    const bool chain = chain_applies(digits);
+    if (chain) {
+        const int rc = prefill_chain_layers(N);
+        if (rc) return rc;
+    }
     for (auto &L : layers_) {
+        if (chain) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         if (kv_f16_)
             BCHK(bitnet_hip_attention_prefill_kv16_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,

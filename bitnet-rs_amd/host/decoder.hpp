@@ -114,6 +114,8 @@ class Decoder {
     // the KV cache already holds positions 0..n-1; last_row (device, [hidden]) is the residual stream
     // of position n-1 or null on ranks that do not own it (then only the position counter moves).
     int finish_prefill(int n, const float *last_row, bool with_logits);
+    bool chain_applies(int digits) const;
+    int prefill_chain_layers(size_t N);
     void set_phase_timing(bool on) { sp_timing_ = on; }
     void phase_times(float out[4]) const {
         for (int i = 0; i < 4; ++i) out[i] = sp_phase_us_[i];
@@ -203,6 +205,11 @@ class Decoder {
     int pf_cap_ = 0;
     float *pf_x_ = nullptr, *pf_qkv_ = nullptr, *pf_att_ = nullptr, *pf_h_ = nullptr;
     void *pf_gemm_ws_ = nullptr, *pf_attn_ws_ = nullptr;
+    // the f16 activation chain of the prompt forward (prefill_chain): f16 rows handed from kernel to kernel, LayerNorm statistics partials
+    int pfc_cap_ = 0;
+    void *pf_xh_ = nullptr, *pf_atth_ = nullptr, *pf_hh_ = nullptr;
+    float *pf_stats_ = nullptr;
+    int prefill_chain_ = -1;  // BITNET_HOST_PREFILL_CHAIN: -1 automatic (the block-scaled format, whose matmul runs on f16 activations anyway), 0 off, 1 on
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;
     static constexpr int kGraphs = 6;

@@ -228,6 +228,25 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
  * that the instance bench.py times (2 digits, 64-token tile) is the one they compared with the oracle. */
 int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode);
 
+/* The prompt forward's f16 ACTIVATION CHAIN (north_star: "2-bit weight unpack x f16 activation dot product"; replaces the reference's
+ * per-row loop T:683-691 / T:924 over many activation rows, K/cpu/quantized_matmul.rs:57-96 for the scaled format): every projection
+ * reads an f16 matrix xh [m_pad][cols] (m_pad = m rounded up to 64; rows >= m are never stored but must be readable) that the kernel
+ * which PRODUCED those activations wrote, so no conversion / quantisation launch sits between two projections.
+ *   ln_gamma != NULL: LayerNorm (no bias, mean-subtracting, T:67-100) of the INPUT, applied after the product: xh must hold
+ *                     f16(gamma * x); stats_in = float2 (sum, sum of squares) partials [n_stats][m_pad] of the exact f32 x over its
+ *                     columns; the matrix must be bound to this gamma (bitnet_hip_weights_bind_ln).
+ *   y (nullable): f32 rows [m][rows]; residual (nullable, may alias y): y = residual + W x (T:1073, T:1125).
+ *   BITNET_HIP_FUSE_SILU_MUL: (gate, up) interleaved handle, outputs have rows / 2 columns (T:756-781).
+ *   yh (nullable): the output as f16 rows [m_pad][rows or rows / 2], multiplied by gamma_out[row] first when given (the NEXT
+ *                  LayerNorm's weight); stats_out (nullable): float2 [rows / 64][m_pad] partials of the f32 outputs for that LayerNorm.
+ * bitnet_hip_matmul_f16_supported: rows % 256 == 0, cols % 256 == 0, code map values in -2..2, no scales or f16 32-block scales.
+ * bitnet_hip_rows_to_f16_dev: the chain's entry (the embedding rows): xh = f16(gamma * x) (gamma nullable) + stats partial 0. */
+int bitnet_hip_matmul_f16_supported(bitnet_hip_weights_t w);
+int bitnet_hip_rows_to_f16_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *xh_dev, float *stats_dev, void *stream);
+int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t w, const void *xh_dev, size_t m, const float *stats_in_dev, size_t n_stats,
+                              const float *ln_gamma_dev, float ln_eps, float *y_dev, const float *residual_dev, int flags, void *yh_dev,
+                              const float *gamma_out_dev, float *stats_out_dev, void *stream);
+
 /* Several uploaded matrices with the same cols / code map / block size as ONE
  * launch: rows concatenated (q|k|v share their input: T:288-290).  interleave16 != 0
  * (exactly two matrices of equal rows % 16 == 0) alternates 16-row tiles a0,b0,a1,b1..
@@ -380,6 +399,13 @@ int bitnet_hip_attention_prefill_kv16_dev(const float *qkv_dev, const float *rop
                                           void *kcache_f16_dev, void *vcache_f16_dev, size_t n_heads, size_t n_kv_heads,
                                           size_t head_dim, size_t max_pos, size_t seq_len, void *workspace_dev,
                                           size_t workspace_bytes, float *out_dev, void *stream);
+/* The same call with a flag word: BITNET_HIP_ATTN_CACHE_F16 = the f16 caches of _kv16_dev; BITNET_HIP_ATTN_OUT_F16 = `out` receives
+ * f16 rows [seq_len][n_heads * head_dim] (the input format of bitnet_hip_matmul_f16_dev: the o-projection reads them as they are). */
+#define BITNET_HIP_ATTN_CACHE_F16 1
+#define BITNET_HIP_ATTN_OUT_F16 2
+int bitnet_hip_attention_prefill_flags_dev(const float *qkv, const float *rope_sin, const float *rope_cos, void *kcache, void *vcache, size_t n_heads,
+                                           size_t n_kv_heads, size_t head_dim, size_t max_pos, size_t seq_len, void *workspace, size_t workspace_bytes,
+                                           void *out, int flags, void *stream);
 /* bitnet_hip_gemv_attn_merge_dev (short contexts) with the QAct outputs of gemv_q_dev */
 int bitnet_hip_gemv_attn_merge_q_dev(bitnet_hip_weights_t w, const float *attn_scratch_dev, size_t n_heads,
                                      size_t n_kv_heads, size_t max_pos, const int32_t *pos_dev, float *y_dev,

@@ -1,0 +1,160 @@
+"""GPU parity of the prompt forward's f16 activation chain (bitnet_hip_matmul_f16_dev, kernels_gemm.hip k_gemm_f16a<.., EPI = 1>; the
+operators it replaces: T:683-691 per-row loop / K/cpu/quantized_matmul.rs:57-96, LayerNorm T:67-100, silu * up T:756-781, residual
+T:1073) against the CPU oracle, through the C ABI.
+
+Error model (written in the gates): an activation element is held as f16 (11-bit significand, rounded to nearest: relative error
+uniform in +-2^-12, rms 2^-12 / sqrt(3)); weights (code map value x f16 block scale) are exact in f16 and products are exact in the
+f32 accumulator, so an output errs by sigma = 2^-12 / sqrt(3) * sqrt(sum_k (w_k x_k)^2) plus f32 accumulation noise.  Gate: 7 sigma per
+output (+ 1e-6 * sum |w_k x_k| for the accumulation order) and cosine >= 0.99999 per row (benches/qk256_gemv.rs:234)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LUT_QK = np.array([-2, -1, 1, 2], np.float64)
+LUT_T = np.array([0, 1, 0, -1], np.float64)
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+
+    return torch
+
+
+def make_matrix(hip, rng, fmt, rows, cols):
+    """-> (handle, dense f64 matrix [rows, cols])"""
+    if fmt == "qk256":
+        stride = cols // 256 * 64
+        qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+        pk = qs.reshape(rows, cols // 4)
+        codes = np.stack([(pk >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(rows, cols)
+        return hip.weights_upload_qk256(qs, rows, cols, stride), LUT_QK[codes]
+    codes = rng.choice(np.array([0, 1, 3], np.uint8), size=(rows, cols), p=[0.5, 0.25, 0.25])
+    packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
+    scales = (1.0 / ((np.arange(rows * (cols // 32)) % 100) + 1)).astype(np.float16).astype(np.float32)
+    dense = LUT_T[codes] * np.repeat(scales.reshape(rows, cols // 32).astype(np.float64), 32, axis=1)
+    return hip.weights_upload_i2s(packed.reshape(-1), scales, rows, cols, 32), dense
+
+
+def gate(got, want, w, xa):
+    """7 sigma of the f16 rounding of the activations + f32 accumulation slack; cosine per row"""
+    sigma = 2.0 ** -12 / np.sqrt(3.0) * np.sqrt((xa.astype(np.float64) ** 2) @ (w ** 2).T)
+    slack = 1e-6 * (np.abs(xa).astype(np.float64) @ np.abs(w).T) + 1e-7
+    bad = np.abs(got - want) > 7.0 * sigma + slack
+    assert not bad.any(), float(np.max(np.abs(got - want) / (7.0 * sigma + slack)))
+    for i in range(got.shape[0]):
+        assert cosine(got[i], want[i]) >= 0.99999, i
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+@pytest.mark.parametrize("rows,cols,m", [(256, 256, 1), (512, 2560, 100), (2560, 768, 64), (768, 6912, 300)])
+def test_f16_chain_plain_residual_and_handover(hip, torch_, fmt, rows, cols, m):
+    """y = residual + W xh (in place), the f16 copy f16(gamma_out * y) and the LayerNorm partials the next projection reads"""
+    rng = np.random.default_rng(rows + cols + m)
+    h, w = make_matrix(hip, rng, fmt, rows, cols)
+    assert hip.matmul_f16_supported(h)
+    mp = -(-m // 64) * 64
+    x = (rng.normal(0, 1, (m, cols)) * np.exp(rng.uniform(-2, 2, (m, 1)))).astype(np.float32)
+    res = rng.normal(0, 1, (m, rows)).astype(np.float32)
+    gout = rng.uniform(0.5, 1.5, rows).astype(np.float32)
+    xh = torch_.zeros(mp, cols, dtype=torch_.float16, device="cuda")
+    hip.rows_to_f16_dev(torch_.from_numpy(x).cuda(), None, m, cols, xh, None)
+    torch_.cuda.synchronize()
+    x16 = x.astype(np.float16)
+    assert np.array_equal(xh[:m].cpu().numpy(), x16)  # round to nearest even, as numpy
+    y = torch_.from_numpy(res).cuda()
+    yh = torch_.full((mp, rows), float("nan"), dtype=torch_.float16, device="cuda")
+    st = torch_.full((rows // 64, mp, 2), float("nan"), device="cuda")
+    hip.matmul_f16_dev(h, xh, m, y=y, residual=y, yh=yh, gamma_out=torch_.from_numpy(gout).cuda(), stats_out=st)
+    torch_.cuda.synchronize()
+    got = y.cpu().numpy()
+    want = res.astype(np.float64) + x16.astype(np.float64) @ w.T
+    assert np.isfinite(got).all()
+    # the activations ARE f16 values here (xh is the input): only accumulation order separates the kernel from the f64 product
+    assert np.max(np.abs(got - want) / (np.abs(x16).astype(np.float64) @ np.abs(w).T + np.abs(res) + 1e-6)) <= 2e-6
+    # hand-over: the f16 copy is the f32 output times gamma_out, rounded once; partials are the 64-row slab sums of the f32 output
+    assert np.array_equal(yh[:m].cpu().numpy(), (got * gout).astype(np.float16))
+    stn = st.cpu().numpy()[:, :m, :]
+    slabs = got.reshape(m, rows // 64, 64).astype(np.float64)
+    # (f32 sums of 64 terms in the kernel: 2^-24 relative per addition, against the sum of the magnitudes)
+    assert np.all(np.abs(stn[:, :, 0].T - slabs.sum(axis=2)) <= 4e-6 * np.abs(slabs).sum(axis=2) + 1e-6)
+    assert np.all(np.abs(stn[:, :, 1].T - (slabs ** 2).sum(axis=2)) <= 4e-6 * (slabs ** 2).sum(axis=2) + 1e-6)
+    if mp > m:
+        assert np.all(st.cpu().numpy()[:, m:, :] == 0)  # padding tokens: zero partials
+    hip.weights_free(h)
+
+
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+def test_f16_chain_layernorm_after_product_and_silu(hip, oracle, torch_, fmt):
+    """qkv-like (LayerNorm -> f32 rows) and gate|up-like (LayerNorm -> silu(gate) * up -> f16 rows) launches at the 2B-4T widths,
+    LayerNorm statistics from one partial (the chain's entry) and from 40 (a producer's slabs), against the oracle's LayerNorm + product"""
+    rng = np.random.default_rng(11)
+    K, N, m = 2560, 512, 96
+    mp = -(-m // 64) * 64
+    ha, wa = make_matrix(hip, rng, fmt, N, K)
+    hb, wb = make_matrix(hip, rng, fmt, N, K)
+    x = rng.normal(0.15, 1.0, (m, K)).astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, K) / (80 if fmt == "qk256" else 4)).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    xn = np.stack([oracle.layernorm(x[i], g, 1e-5) for i in range(m)]).astype(np.float64)
+    ya, yb = xn @ wa.T, xn @ wb.T
+    xd = torch_.from_numpy(x).cuda()
+    xh = torch_.zeros(mp, K, dtype=torch_.float16, device="cuda")
+    st1 = torch_.zeros(1, mp, 2, device="cuda")
+    hip.rows_to_f16_dev(xd, gd, m, K, xh, st1)
+    # the same statistics as 40 slab partials (what an o- / down-projection leaves)
+    st40 = torch_.zeros(40, mp, 2, device="cuda")
+    sl = x.reshape(m, 40, 64).astype(np.float64)
+    st40[:, :m, 0] = torch_.from_numpy(sl.sum(axis=2).T.astype(np.float32)).cuda()
+    st40[:, :m, 1] = torch_.from_numpy((sl ** 2).sum(axis=2).T.astype(np.float32)).cuda()
+    hc = hip.weights_concat([ha, hb])
+    hip.weights_bind_ln(hc, gd)
+    xg = (x * g).astype(np.float64)  # what the f16 rounding acts on: sigma is taken over gamma * x, the mean term is exact
+    wcat = np.concatenate([wa, wb], axis=0)
+    for st, n_st in ((st1, 1), (st40, 40)):
+        y = torch_.full((m, 2 * N), float("nan"), device="cuda")
+        hip.matmul_f16_dev(hc, xh, m, stats_in=st, n_stats=n_st, ln_gamma=gd, ln_eps=1e-5, y=y)
+        torch_.cuda.synchronize()
+        got = y.cpu().numpy()
+        denom = np.sqrt(x.astype(np.float64).var(axis=1, keepdims=True) + 1e-5)
+        sigma = 2.0 ** -12 / np.sqrt(3.0) * np.sqrt((xg ** 2) @ (wcat ** 2).T) / denom
+        want = np.concatenate([ya, yb], axis=1)
+        slack = 2e-6 * (np.abs(xg) @ np.abs(wcat).T) / denom + 1e-6
+        assert np.all(np.abs(got - want) <= 7.0 * sigma + slack), (n_st, float(np.max(np.abs(got - want) / (7.0 * sigma + slack))))
+        for i in range(m):
+            assert cosine(got[i], want[i]) >= 0.99999
+    hg = hip.weights_concat([ha, hb], interleave16=True)
+    hip.weights_bind_ln(hg, gd)
+    hh = torch_.full((mp, N), float("nan"), dtype=torch_.float16, device="cuda")
+    yf = torch_.full((m, N), float("nan"), device="cuda")
+    hip.matmul_f16_dev(hg, xh, m, stats_in=st40, n_stats=40, ln_gamma=gd, ln_eps=1e-5, y=yf, flags=1, yh=hh)
+    torch_.cuda.synchronize()
+    want = ya / (1 + np.exp(-ya)) * yb
+    got = yf.cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 2e-3 * np.max(np.abs(want))
+    for i in range(m):
+        assert cosine(got[i], want[i]) >= 0.99999
+    assert np.array_equal(hh[:m].cpu().numpy(), got.astype(np.float16))
+    with pytest.raises(Exception, match="bound gamma"):
+        hip.matmul_f16_dev(hc, xh, m, stats_in=st1, n_stats=1, ln_gamma=torch_.from_numpy(g.copy()).cuda(), ln_eps=1e-5, y=yf)
+    for h in (ha, hb, hc, hg):
+        hip.weights_free(h)
+
+
+def test_f16_chain_refuses_what_it_cannot_take(hip, torch_):
+    rng = np.random.default_rng(3)
+    n, k = 100, 512  # rows % 256 != 0
+    qs = rng.integers(0, 256, n * (k // 256) * 64, dtype=np.uint8)
+    h = hip.weights_upload_qk256(qs, n, k, k // 256 * 64)
+    assert not hip.matmul_f16_supported(h)
+    xh = torch_.zeros(64, k, dtype=torch_.float16, device="cuda")
+    y = torch_.zeros(10, n, device="cuda")
+    with pytest.raises(Exception, match="does not take the f16 chain"):
+        hip.matmul_f16_dev(h, xh, 10, y=y)
+    hip.weights_free(h)
