@@ -494,9 +494,13 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     fu.ln_eps = ln_eps;
     fu.residual = residual_dev;
     fu.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    fu.x_f16 = (flags & BITNET_HIP_FUSE_X_F16) != 0;
+    fu.y_f16 = (flags & BITNET_HIP_FUSE_Y_F16) != 0;
     if (fu.silu_mul && (!w->paired || residual_dev))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
                          "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    if ((fu.x_f16 || fu.y_f16) && (!gemm_supported(*w) || (fu.y_f16 && (!fu.silu_mul || (w->rows / 2) % 4 != 0)) || (fu.x_f16 && ln_gamma_dev)))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_X_F16 (no LayerNorm) / FUSE_Y_F16 (with FUSE_SILU_MUL) need a matrix the tiled matmul takes");
     if (!gemm_supported(*w)) return run_gemv(*w, x_dev, y_dev, m, fu, (hipStream_t)stream);  // 32-element block scales: row by row
     const size_t need = gemm_workspace_bytes(m, w->cols, digits);
     if (!workspace_dev || workspace_bytes < need)
@@ -507,6 +511,8 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
         if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
     }
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue && (fu.x_f16 || fu.y_f16))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_X_F16 / FUSE_Y_F16: this matrix runs on the f16 matrix cores at this digit count: use bitnet_hip_matmul_f16_dev");
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
     BH_GUARD_END

@@ -93,6 +93,7 @@ struct GemvFusion {
     float ln_eps = 0.0f;
     const float *residual = nullptr;  // y = residual + W x
     bool silu_mul = false;            // rows are (gate tile, up tile) pairs: y = silu(gate) * up
+    bool x_f16 = false, y_f16 = false;  // prefill matmul only: x rows / the silu * up output are f16 (BITNET_HIP_FUSE_X_F16 / _Y_F16)
     // x = the decode attention's output, merged from its chunk records by the GEMV itself (no combine launch):
     // records of launch_attn_decode(..., combine = false); contexts of at most 4 records
     const float *attn_rec = nullptr;

@@ -62,7 +62,8 @@ struct GemmArgs {
 };
 
 struct QuantArgs {
-    const float *x;  // [m, cols]
+    const float *x;  // [m, cols] f32 -- or f16 when x_f16 (rows the producing kernel already rounded: attention output, silu * up)
+    int x_f16 = 0;
     int m, m_pad, cols, kp;
     const float *ln_gamma;
     float ln_eps;
@@ -103,7 +104,13 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + 256 * i, ci = idx < nvec ? idx : nvec - 1;
-        v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        if (p.x_f16) {  // (wave-uniform)
+            typedef _Float16 qh4 __attribute__((ext_vector_type(4)));
+            const qh4 hv = *reinterpret_cast<const qh4 *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)rr * p.cols + 4 * ci);
+            v[i] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {
+            v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        }
         if (idx >= nvec || !live) v[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
     if (p.ln_gamma) {
@@ -288,7 +295,18 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
                 r[pr][j] = gv / (1.0f + expf(-gv)) * uv;
             }
         const int ra = 16 * (tile0 >> 1) + 4 * g;  // tile0 / 2 = the wave's first tile of the [m, rows / 2] output
-        if ((half_rows & 3) == 0) {
+        if (p.yh) {  // f16 rows for the down-projection's quantiser: half the bytes written here and read there (half_rows % 4 == 0 checked by the launcher)
+            typedef _Float16 sh4 __attribute__((ext_vector_type(4)));
+            if (token < p.m) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    sh4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[pr][j], -65504.0f, 65504.0f);
+                    *reinterpret_cast<sh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
+                }
+            }
+        } else if ((half_rows & 3) == 0) {
             store_tile_pair(p.y, nullptr, half_rows, p.m, tok0, c, ra, r[0], r[1]);
         } else if (token < p.m) {
 #pragma unroll
@@ -1188,6 +1206,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     q.kp = (int)(div_ceil(w.cols, 256) * 256);
     q.ln_gamma = fu.ln_gamma;
     q.ln_eps = fu.ln_eps;
+    q.x_f16 = fu.x_f16 ? 1 : 0;
     uint8_t *ws = static_cast<uint8_t *>(workspace);
     ws = reinterpret_cast<uint8_t *>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     q.inv_scale = reinterpret_cast<float *>(ws);
@@ -1206,6 +1225,11 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
+    if (fu.x_f16 || fu.y_f16) {  // f16 hand-over: the int8 digit form's quantiser reads f16 rows; silu * up goes out as f16 rows
+        const bool f16_form = (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite);
+        if (f16_form || (fu.y_f16 && (!fu.silu_mul || ((w.rows >> 1) & 3) != 0))) return hipErrorInvalidValue;
+        if (fu.y_f16) a.yh = reinterpret_cast<_Float16 *>(y), a.y = nullptr;
+    }
     if (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite) return launch_gemm_f16(w, q, a, stream);
     {
         static const int f16a_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16A"); return e ? atoi(e) : 0; }();

@@ -737,7 +737,22 @@ bool Decoder::chain_applies(int digits) const {
     return prefill_chain_ == 1 || scaled_all;
 }
 
-int Decoder::prefill_chain_layers(size_t N) {
+// The int8 digit form (QK256's prompt matmul) keeps its row quantisers, but the two inputs no LayerNorm touches travel as f16: the
+// attention writes f16 rows, gate|up's epilogue writes f16(silu(gate) * up), and the o- / down-projection's quantisers read them
+// (BITNET_HIP_FUSE_X_F16 / _Y_F16): half the bytes on both sides of the two largest hand-overs.  digits = 2 only (an f16 row holds 11
+// bits of each element: more than the 2-digit planes take from most elements, fewer than 3 or 4 digits).
+bool Decoder::handover16_applies(int digits) const {
+    if (digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
+    for (const auto &L : layers_)
+        for (bitnet_hip_weights_t h : {L.o, L.gateup, L.down}) {
+            size_t rows = 0, cols = 0, ab = 0;
+            if (!h || bitnet_hip_weights_info(h, &rows, &cols, &ab) != 0) return false;
+            if (ab != rows * (cols / 4) || cols % 256 != 0 || rows % 16 != 0) return false;  // unscaled 2-bit codes, the tiled matmul's shapes
+        }
+    return c_.ffn % 4 == 0;
+}
+
+int Decoder::ensure_chain_buffers(size_t N) {
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, F = c_.ffn;
     const size_t NP = (N + 63) / 64 * 64, nst = H / 64;
     hipStream_t s = (hipStream_t)stream_;
@@ -757,6 +772,16 @@ int Decoder::prefill_chain_layers(size_t N) {
         HCHK(hipMemsetAsync(pf_hh_, 0, NP * F * 2, s));
         HCHK(hipMemsetAsync(pf_stats_, 0, nst * NP * 2 * sizeof(float), s));
         pfc_cap_ = (int)NP;
+    }
+    return 0;
+}
+
+int Decoder::prefill_chain_layers(size_t N) {
+    const size_t H = c_.hidden, nst = H / 64;
+    hipStream_t s = (hipStream_t)stream_;
+    {
+        const int rc = ensure_chain_buffers(N);
+        if (rc) return rc;
     }
     BCHK(bitnet_hip_rows_to_f16_dev(pf_x_, layers_[0].attn_norm, N, H, pf_xh_, pf_stats_, s));
     size_t n_stats = 1;
@@ -828,9 +853,24 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         const int rc = prefill_chain_layers(N);
         if (rc) return rc;
     }
+    const bool h16 = !chain && handover16_applies(digits);
+    if (h16) {
+        const int rc = ensure_chain_buffers(N);
+        if (rc) return rc;
+    }
     for (auto &L : layers_) {
         if (chain) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        if (h16) {
+            BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,
+                                                        (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_atth_,
+                                                        (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | BITNET_HIP_ATTN_OUT_F16, s));
+            BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+            BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, (float *)pf_hh_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | BITNET_HIP_FUSE_Y_F16, digits,
+                                             pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+            BCHK(bitnet_hip_matmul_fused_dev(L.down, (const float *)pf_hh_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+            continue;
+        }
         if (kv_f16_)
             BCHK(bitnet_hip_attention_prefill_kv16_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
                                                        (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));

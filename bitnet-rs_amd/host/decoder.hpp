@@ -115,6 +115,8 @@ class Decoder {
     // of position n-1 or null on ranks that do not own it (then only the position counter moves).
     int finish_prefill(int n, const float *last_row, bool with_logits);
     bool chain_applies(int digits) const;
+    bool handover16_applies(int digits) const;
+    int ensure_chain_buffers(size_t N);
     int prefill_chain_layers(size_t N);
     void set_phase_timing(bool on) { sp_timing_ = on; }
     void phase_times(float out[4]) const {

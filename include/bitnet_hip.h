@@ -215,7 +215,12 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
  * matmul on the matrix cores).  Same fusions as gemv_fused_dev, per row.  `digits` = base-256
  * fixed-point digits per activation (4: the GEMV's 30 bits; 3: 22 bits; 2: 14 bits -- on BitNet32-F16 matrices (32-element blocks
  * with f16 scales) digits = 2 means f16 activations with one power-of-two scale per row, on the f16 matrix cores).
- * The int8 digit planes live in a caller-owned device workspace. */
+ * The int8 digit planes live in a caller-owned device workspace.
+ * flags (beside BITNET_HIP_FUSE_SILU_MUL), int8 digit form only -- f16 hand-over between the prompt forward's launches:
+ *   BITNET_HIP_FUSE_X_F16: x_dev holds f16 rows [m][cols] (the attention's f16 output, the f16 silu * up rows); no LayerNorm with it
+ *   BITNET_HIP_FUSE_Y_F16: with FUSE_SILU_MUL, y_dev receives the product as f16 rows [m][rows / 2] */
+#define BITNET_HIP_FUSE_X_F16 2
+#define BITNET_HIP_FUSE_Y_F16 4
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
 int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev,

@@ -221,3 +221,38 @@ def test_matmul_on_block256_scales_keeps_one_copy_of_the_codes(hip, torch_):
     code_bytes = -(-n // 16) * (k // 256) * 1024
     assert before < 2 * code_bytes
     hip.weights_free(h)
+
+
+def test_f16_handover_flags_of_the_digit_form(hip, torch_):
+    """BITNET_HIP_FUSE_X_F16 / _Y_F16 (the prompt forward's hand-over on the int8 digit form): f16 input rows give, bit for bit, what the
+    same values as f32 rows give; the f16 silu * up output is the f32 output rounded once.  Refused where they have no meaning."""
+    rng = np.random.default_rng(8)
+    K, N, m = 1024, 512, 70
+    stride = K // 256 * 64
+    qa = rng.integers(0, 256, N * stride, dtype=np.uint8)
+    qb = rng.integers(0, 256, N * stride, dtype=np.uint8)
+    ha, hb = hip.weights_upload_qk256(qa, N, K, stride), hip.weights_upload_qk256(qb, N, K, stride)
+    hg = hip.weights_concat([ha, hb], interleave16=True)
+    x16 = rng.normal(0, 1, (m, K)).astype(np.float16)
+    x32 = x16.astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, K) / 80).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    wsb = hip.matmul_workspace_bytes(m, K, 2)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    ya, yb = torch_.empty(m, N, device="cuda"), torch_.empty(m, N, device="cuda")
+    hip.matmul_fused_dev(ha, torch_.from_numpy(x32).cuda(), ya, m, ws, wsb, digits=2)
+    hip.matmul_fused_dev(ha, torch_.from_numpy(x16).cuda(), yb, m, ws, wsb, digits=2, flags=2)
+    torch_.cuda.synchronize()
+    assert np.array_equal(ya.cpu().numpy(), yb.cpu().numpy())
+    yf = torch_.empty(m, N, device="cuda")
+    yh = torch_.full((m, N), float("nan"), dtype=torch_.float16, device="cuda")
+    hip.matmul_fused_dev(hg, torch_.from_numpy(x32).cuda(), yf, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, flags=1, digits=2)
+    hip.matmul_fused_dev(hg, torch_.from_numpy(x32).cuda(), yh, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, flags=1 | 4, digits=2)
+    torch_.cuda.synchronize()
+    assert np.array_equal(yh.cpu().numpy(), yf.cpu().numpy().astype(np.float16))
+    with pytest.raises(Exception, match="FUSE_X_F16"):
+        hip.matmul_fused_dev(ha, ya, yb, m, ws, wsb, digits=2, flags=4)  # Y_F16 without SILU_MUL
+    with pytest.raises(Exception, match="FUSE_X_F16"):
+        hip.matmul_fused_dev(ha, ya, yb, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, digits=2, flags=2)  # X_F16 with a LayerNorm
+    for h in (ha, hb, hg):
+        hip.weights_free(h)
