@@ -211,7 +211,7 @@ def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
             "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
-def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int = 12, launches: int | None = None):
+def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int = 12, launches: int | None = None, isolated_only: bool = False):
     """The decode GEMV's STREAMING rate: the very kernel instance of the fused gate|up launch (k_gemv_q<8, 5, SC, LN, 1>: LayerNorm
     after the product, silu*mul, QAct in and out) over ONE matrix of `layers_worth` gate|up matrices laid end to end -- 64 x
     13824 rows x 2560 columns = 566 MB of 2-bit codes (+ 142 MB of f16 block scales for BitNet32-F16), larger than every cache
@@ -257,7 +257,7 @@ def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int =
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     bursts, singles = [], []
     if launches is None:
-        for _ in range(5):  # throughput reading: `reps` launches back to back -- one launch's drain overlaps the next one's fill
+        for _ in range(0 if isolated_only else 5):  # throughput reading: `reps` launches back to back -- one launch's drain overlaps the next one's fill
             e0.record(stream)
             for _ in range(reps):
                 launch()
@@ -276,7 +276,11 @@ def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int =
     hip.weights_free(h)
     out = {"kernel": "k_gemv_q (the decode step's fused LayerNorm -> gate|up GEMV -> silu*mul instance, one launch over the whole matrix)",
            "format": "BitNet32-F16" if fmt == "i2s" else "QK256", "rows": 2 * F, "cols": K, "bytes_per_launch": int(abytes)}
-    if singles:
+    if singles and not bursts:  # the profiler's trace pass (--stream-isolated): the kernel table then holds isolated launches only
+        us_k = float(np.median(singles))
+        out.update({"us_per_launch": round(us_k, 2), "achieved": round(abytes / us_k / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(abytes / us_k / 1e3 / HBM_PEAK_GBS, 4), "timing": f"isolated launches only, median of {len(singles)}"})
+    elif singles:
         us_k, us_b, us_best = float(np.median(singles)), float(np.median(bursts)), float(min(bursts))
         gbs = abytes / us_k / 1e3
         out.update({"us_per_launch": round(us_k, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -558,6 +562,8 @@ def main():
     ap.add_argument("--stream-layers", type=int, default=64, help="i2s_stream: gate|up matrices laid end to end (64 = 708 MB BitNet32-F16 / 566 MB QK256)")
     ap.add_argument("--stream-launches", type=int, default=None, help="stream workload only: a fixed number of launches and no timing (profiler counter passes)")
     ap.add_argument("--stream-format", default="i2s", choices=["i2s", "qk256"])
+    ap.add_argument("--stream-isolated", action="store_true", help="stream workload: isolated launches only, no back-to-back bursts (the profiler's trace pass: "
+                    "rocprofv3's per-kernel duration is then the one i2s_stream.us_per_launch reports)")
     ap.add_argument("--no-stream", action="store_true", help="skip the i2s_stream object of the default line")
     ap.add_argument("--no-exact-check", action="store_true", help="skip exact_step_check (the profiler passes: its reference-order kernels would fill the kernel table)")
     ap.add_argument("--prompt", type=int, default=None, help="prompt length (default 128; 4096 for c4)")
@@ -612,7 +618,7 @@ def main():
     global PROMPT_LEN
     PROMPT_LEN = args.prompt or {"c4": 4096, "c5": 8192}.get(args.workload, 128)
     if args.workload == "stream":  # the streaming-rate probe alone (tools/profile_round.sh runs its counter passes through this)
-        res = i2s_stream(hip, synth, args.stream_format, args.stream_layers, launches=args.stream_launches)
+        res = i2s_stream(hip, synth, args.stream_format, args.stream_layers, launches=args.stream_launches, isolated_only=args.stream_isolated)
         if rank == 0:
             print(json.dumps({"metric": "I2_S matmul HBM GB/s (% roofline), streaming regime", "value": res.get("achieved"), "unit": "GB/s", "n_gpus": n_gpus,
                               "steps": res.get("launches_timed"), "warmup": 1, "higher_is_better": True, "vs_baseline": None, "dtype": "i8 MFMA on QAct",

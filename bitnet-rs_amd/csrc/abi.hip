@@ -1133,7 +1133,7 @@ int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q, size_t ld_q,
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "workspace too small: expected %zu, got %zu", need, workspace_bytes);
     BH_HIP_TRY(launch_attn_prefill(q, (int)ld_q, q_block_pos, (int)n_q, static_cast<const float *>(kv_gathered), (int)(2 * n_kv_heads * head_dim), (int)n_ctx,
                                    rope_sin, rope_cos, static_cast<float *>(kcache), static_cast<float *>(vcache), (int)n_heads, (int)n_kv_heads, (int)head_dim,
-                                   (int)max_pos, workspace, workspace_bytes, out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0, cache_f16 ? 1 : 0, phase));
+                                   (int)max_pos, workspace, workspace_bytes, out, (hipStream_t)stream, (int)world, kv_is_f16 ? 1 : 0, cache_f16 & 3, phase));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }

@@ -1012,6 +1012,13 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
     HCHK(hipEventRecord(ev0.e, s));
     BCHK(bitnet_hip_embed_f16_dev(embed_, sp_tokens_, nullptr, N, H, (size_t)c_.vocab, pf_x_, s));
     const size_t ld = QD + 2 * KD, per_rank = N * 2 * KD * esz;
+    const bool h16 = handover16_applies(digits);  // f16 hand-over of the attention output and of silu * up (Decoder::prefill explains)
+    if (h16) {
+        const int rc = ensure_chain_buffers(N);
+        if (rc) return rc;
+    }
+    float *att_out = h16 ? static_cast<float *>(pf_atth_) : pf_att_;
+    const int aflags = (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | (h16 ? BITNET_HIP_ATTN_OUT_F16 : 0);
     for (auto &L : layers_) {
         HCHK(mark(0, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
@@ -1031,7 +1038,7 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
             HCHK(mark(7, (hipStream_t)comm_stream_));
             HCHK(hipEventRecord((hipEvent_t)sp_ev_gather_, (hipStream_t)comm_stream_));
             BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
-                                                                 rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, 1, s));
+                                                                 rope_cos_, L.kcache, L.vcache, aflags, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, att_out, 1, s));
             HCHK(mark(2, s));
             HCHK(hipStreamWaitEvent(s, (hipEvent_t)sp_ev_gather_, 0));
             HCHK(mark(3, s));
@@ -1042,13 +1049,15 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
             HCHK(mark(7, s));
         }
         BCHK(bitnet_hip_attention_prefill_gathered_phase_dev(pf_qkv_, ld, sp_block_pos_, N, sp_kv_all_, (size_t)n, (size_t)world, wire_f16 ? 1 : 0, rope_sin_,
-                                                             rope_cos_, L.kcache, L.vcache, kv_f16_ ? 1 : 0, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_,
+                                                             rope_cos_, L.kcache, L.vcache, aflags, NH, NK, D, MP, pf_attn_ws_, pf_attn_ws_bytes_, att_out,
                                                              world > 1 ? 2 : 0, s));
         HCHK(mark(4, s));
-        BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
-        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
+        const int xf = h16 ? BITNET_HIP_FUSE_X_F16 : 0, yf = h16 ? BITNET_HIP_FUSE_Y_F16 : 0;
+        float *h_buf = h16 ? static_cast<float *>(pf_hh_) : pf_h_;
+        BCHK(bitnet_hip_matmul_fused_dev(L.o, att_out, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, h_buf, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | yf, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
-        BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.down, h_buf, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         HCHK(mark(5, s));
         ++li;
     }

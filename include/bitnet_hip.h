@@ -458,7 +458,8 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q_dev, size_t ld_q, c
                                               float *out_dev, void *stream);
 /* The same in two steps, so that the all-gather of k|v can run on ANOTHER stream beside the query-side work: phase 1 prepares the
  * query slabs only (RoPE, f16; kv_gathered_dev is not read), phase 2 does the k / v slabs, the cache fill and the attention on
- * the workspace phase 1 left; phase 0 = both (the call above). */
+ * the workspace phase 1 left; phase 0 = both (the call above).  cache_f16 is a flag word here: BITNET_HIP_ATTN_CACHE_F16 (bit 0, as
+ * above) | BITNET_HIP_ATTN_OUT_F16 (bit 1: out_dev receives f16 rows, the o-projection's FUSE_X_F16 / f16-chain input). */
 int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q_dev, size_t ld_q, const int32_t *q_block_pos_dev, size_t n_q,
                                                     const void *kv_gathered_dev, size_t n_ctx, size_t world, int kv_is_f16,
                                                     const float *rope_sin_dev, const float *rope_cos_dev, void *kcache_dev,

@@ -19,9 +19,9 @@
 #   usage: tools/profile_round.sh <tag> [passes]   passes: any of c2 c3 c4 stream prefill provider (default: all)
 # The program sits directly behind `--`: no env / bash -c hop under rocprofv3.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
-PASSES=${*:-c2 c3 c4 stream prefill provider}
+PASSES=${*:-stream prefill c2 c3 c4 provider}   # stream and prefill first: their traffic_*.json (written into profiles/ as each pass ends) are what the bench lines of c2 / c4 quote
 export TMPDIR=/tmp
 SIT=$(date +%Y%m%d_%H%M%S)
 OUT=gpurun_out/prof_${TAG}_${SIT}
@@ -38,15 +38,15 @@ for WL in $PASSES; do
     D="$OUT/$WL"
     case $WL in
     c2|c3|c4)
-        TRACE_ARGS="--workload $WL --steps 64 --warmup 4 --no-cpu-baseline --no-stream --no-exact-check"
-        PMC_ARGS="--workload $WL --prompt 8 --steps 8 --warmup 0 --no-cpu-baseline --no-stream --no-exact-check"
+        TRACE_ARGS="--workload $WL --steps 64 --warmup 4 --no-cpu-baseline --no-stream --no-exact-check --no-also"
+        PMC_ARGS="--workload $WL --prompt 8 --steps 8 --warmup 0 --no-cpu-baseline --no-stream --no-exact-check --no-also"
         if [ "$WL" = c4 ]; then PMC_ARGS="--workload c4 --steps 8 --warmup 0 --no-cpu-baseline --no-stream --no-exact-check --layers 4"; fi
         three_passes "$D" python3 bench.py || exit 1
         python3 bench.py --workload $WL --steps 128 --warmup 8 > "$D/bench.json" 2> "$D/bench.err" || { tail -5 "$D/bench.err"; exit 1; }
         python3 tools/profile_summary.py "$D" "$TAG" "$WL" || exit 1 ;;
     stream)
         for F in i2s qk256; do
-            TRACE_ARGS="--workload stream --stream-format $F"
+            TRACE_ARGS="--workload stream --stream-format $F --stream-isolated"   # isolated launches: the per-kernel duration bench.py's i2s_stream.us_per_launch reports
             PMC_ARGS="--workload stream --stream-format $F --stream-launches 6"
             three_passes "${D}_$F" python3 bench.py || exit 1
             python3 tools/profile_summary.py "${D}_$F" "$TAG" "stream_$F" || exit 1
