@@ -27,7 +27,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ATTN = "_ZN10bitnet_hip14k_prefill_attnILi4ELi4ELi2EEEvNS_11PrefillArgsE"
 GEMM64 = "_ZN10bitnet_hip11k_gemm_mfmaILi2ELi4ELi0ELi2ELi1EEEvNS_8GemmArgsE"
 GEMM32 = "_ZN10bitnet_hip11k_gemm_mfmaILi2ELi2ELi0ELi2ELi1EEEvNS_8GemmArgsE"
-GEMMF16 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4EEEvNS_8GemmArgsEj"
+GEMMF16 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1EEEvNS_8GemmArgsEj"  # the f16 chain instance (BitNet32-F16, 64-token tile, chain epilogues)
 
 
 def _compile(src, tmp):
