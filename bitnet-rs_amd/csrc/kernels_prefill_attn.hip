@@ -61,6 +61,7 @@ struct PrefillArgs {
     int zz_world, zz_chunk;  // ranks, tokens per chunk (T = 2 * world * chunk; chunk % 64 == 0)
     int kv_f16;              // the k|v rows travelled as f16 (half the bytes on the wire); k / v then point at _Float16
     int cache_f16;           // the decode caches hold f16 (kernels_attn.hip KV16 layout)
+    int head_fast;           // grid = (head groups, query groups): the dispatch order walks ALL heads' longest blocks first (see launch_attn_kernel)
     int out_f16;             // `out` holds _Float16 (same element strides): the o-projection's f16 chain reads it as it is (kernels_gemm.hip k_gemm_f16a)
     // key split: the key tiles of a query block are dealt to `ksplit` workgroups (blockIdx.z), each leaving an un-normalised partial
     // (o, m, l) that k_prefill_merge combines -- for launches whose query blocks alone would not fill the chip (one rank's 1024
@@ -247,9 +248,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     static_assert(NW == 4, "tile staging deals 32 pieces to 4 waves");
     extern __shared__ __attribute__((aligned(16))) uint8_t kv_lds[];  // [2][K tile | V^T tile]
     __shared__ int s_last;
-    const int qg = (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
+    const int qg = p.head_fast ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)gridDim.x - 1 - (int)blockIdx.x;  // long (late) blocks first
+    const int hg = p.head_fast ? blockIdx.x : blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y * HW + wave % HW, kvh = h / (p.n_heads / p.n_kv);  // HW divides the group: one KV head per workgroup
+    const int h = hg * HW + wave % HW, kvh = h / (p.n_heads / p.n_kv);  // HW divides the group: one KV head per workgroup
     const int qbase = qg * QG + (wave / HW) * 16 * NQ;            // first query row of this wave (16 NQ rows inside one 64-row block)
     const int blk64 = qbase >> 6;                                 // the 64-row block the wave's rows lie in
     const int bpos = (p.q_block_pos ? p.q_block_pos[blk64 < (p.nq + kQB - 1) / kQB ? blk64 : 0] : blk64 * kQB) + (qbase & 63);
@@ -588,6 +590,14 @@ static hipError_t launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
         ak = k_prefill_attn<1, 4, 2>;
         grid = dim3((unsigned)(p.nq_pad / 128), (unsigned)p.n_heads, z);
     }
+    // Workgroups are dispatched in linear id order (x fastest).  With the query groups in x, head group 0's blocks all start before head
+    // group 1's first: on a causal prompt (640 workgroups for 512 slots at 4096 tokens x 20 heads) the LAST head group's longest blocks only
+    // start once earlier groups' short ones have finished, and stand alone at the end.  With the head groups in x the order is longest
+    // blocks of every head first, shortest last (longest-processing-time order over the whole launch).
+    static const bool head_fast = !(getenv("BITNET_HIP_ATTN_HEAD_FAST") && atoi(getenv("BITNET_HIP_ATTN_HEAD_FAST")) == 0);
+    PrefillArgs pa = p;
+    pa.head_fast = head_fast ? 1 : 0;
+    if (head_fast) grid = dim3(grid.y, grid.x, grid.z);
     {
         // two tile buffers = 64 KiB of dynamic LDS (+ a static word): raised once per kernel; entry points may run concurrently
         static std::mutex raised_mu;
@@ -599,7 +609,7 @@ static hipError_t launch_attn_kernel(const PrefillArgs &p, hipStream_t stream) {
             raised.insert((const void *)ak);
         }
     }
-    hipLaunchKernelGGL(ak, grid, dim3(256), 2 * kKVBuf, stream, p);
+    hipLaunchKernelGGL(ak, grid, dim3(256), 2 * kKVBuf, stream, pa);
     if (p.ksplit > 1)
         hipLaunchKernelGGL(k_prefill_merge, dim3((unsigned)div_ceil((size_t)p.nq * p.n_heads * 32, 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
@@ -709,7 +719,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.causal = causal;
     p.scale = scale;
     p.q_block_pos = nullptr;
-    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = p.out_f16 = p.phase = 0;
+    p.zz_world = p.zz_chunk = p.kv_f16 = p.cache_f16 = p.out_f16 = p.head_fast = p.phase = 0;
     p.nq = seq;
     p.nq_pad = (int)(div_ceil((size_t)seq, kQPad) * kQPad);
     p.rope_sin = p.rope_cos = nullptr;
