@@ -284,8 +284,9 @@ def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int =
         us_k, us_b, us_best = float(np.median(singles)), float(np.median(bursts)), float(min(bursts))
         gbs = abytes / us_k / 1e3
         out.update({"us_per_launch": round(us_k, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "timing": f"HIP events on the launch stream around ONE launch at a time, median of {len(singles)} (the per-kernel duration; "
-                              "compare us_per_kernel_rocprof)",
+                    "timing": f"HIP events on the launch stream around ONE launch at a time (stream idle before it), median of {len(singles)}: the kernel's "
+                              "own duration plus the idle queue's dispatch latency (a few us) -- the conservative reading; us_per_kernel_rocprof = rocprofv3's "
+                              "begin-to-end duration of the same isolated launches (profiles/r04_stream_*: bench.py --workload stream --stream-isolated)",
                     "burst": {"launches": reps, "bursts": len(bursts), "us_per_launch_median": round(us_b, 2), "us_per_launch_best": round(us_best, 2),
                               "frac_median": round(abytes / us_b / 1e3 / HBM_PEAK_GBS, 4), "frac_best": round(abytes / us_best / 1e3 / HBM_PEAK_GBS, 4),
                               "note": "back-to-back launches: the first workgroups of launch n + 1 start on the CUs launch n's last round has left, so the "
