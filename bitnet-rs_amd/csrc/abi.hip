@@ -496,6 +496,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     fu.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
     fu.x_f16 = (flags & BITNET_HIP_FUSE_X_F16) != 0;
     fu.y_f16 = (flags & BITNET_HIP_FUSE_Y_F16) != 0;
+    fu.int8_form = (flags & BITNET_HIP_FUSE_INT8_DIGITS) != 0;
     if (fu.silu_mul && (!w->paired || residual_dev))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
                          "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");

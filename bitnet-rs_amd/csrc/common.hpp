@@ -94,6 +94,7 @@ struct GemvFusion {
     const float *residual = nullptr;  // y = residual + W x
     bool silu_mul = false;            // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     bool x_f16 = false, y_f16 = false;  // prefill matmul only: x rows / the silu * up output are f16 (BITNET_HIP_FUSE_X_F16 / _Y_F16)
+    bool int8_form = false;             // prefill matmul only: keep the int8 digit planes (BITNET_HIP_FUSE_INT8_DIGITS: no fp6 / f16 form)
     // x = the decode attention's output, merged from its chunk records by the GEMV itself (no combine launch):
     // records of launch_attn_decode(..., combine = false); contexts of at most 4 records
     const float *attn_rec = nullptr;
@@ -191,7 +192,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
 // the tile form launch_gemm_mfma chose on this thread's last call: digits, tokens per wave tile (16 x TTW), waves per workgroup,
 // weight-scale mode (0 none, 1 per 256-block, 2 masked K = 64 per 32-block, 3 K = 32 MFMA with f16 scale tiles)
 struct GemmTileChoice {
-    int digits = 0, wave_tokens = 0, waves = 0, scale_mode = 0;
+    int digits = 0, wave_tokens = 0, waves = 0, scale_mode = 0, wave_rows = 64;
 };
 extern thread_local GemmTileChoice g_last_gemm_tile;
 extern unsigned long long *g_mfma_stamps;  // diagnostic build only

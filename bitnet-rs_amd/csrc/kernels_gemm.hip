@@ -91,8 +91,14 @@ __device__ __forceinline__ double qwave_sum_d(double v) {
 
 // ---- activation rows -> digit planes --------------------------------------------------------
 // 256 threads per row, NV float4 per thread (cols <= 1024 * NV).
-template <int NDIG, int NV>
+// FP6 = 1 (NDIG = 2 only): the SAME 15-bit integer q = rint(x 2^(13 - E)) written as three balanced base-32 digits in fp6 (e2m3)
+// for k_gemm_fp6 below -- q = d0 + 32 d1 + 1024 d2, d0, d1 in [-16, 15], |d2| <= 16; the fp6 code of n / 8 is sign | |n| (the
+// subnormals and the first two binades of e2m3 are contiguous), so a digit is stored as a 6-bit sign-magnitude integer.  Row layout:
+// [256-block][lane group g 4][digit 3][MFMA m 2][chunk of 8 columns 4][6 bytes] = 576 bytes per block; inside a chunk the column at
+// offset o sits at k-slot 2 (o & 3) + (o >> 2) -- the order in which the weight expansion leaves its fp4 nibbles (expand16_fp4).
+template <int NDIG, int NV, int FP6 = 0>
 __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
+    static_assert(!FP6 || NDIG == 2, "the fp6 form carries the 2-digit form's integer");
     constexpr int S = 8 * NDIG - 3;
     __shared__ double stat[8];
     __shared__ float smax[4];
@@ -157,6 +163,43 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
     const float sc = __uint_as_float((uint32_t)(254 + S - be) << 23);     // 2^(S - E)
     const float inv_s = __uint_as_float((uint32_t)(be - S) << 23);        // 2^(E - S)
     if (tid == 0) p.inv_scale[row] = live ? inv_s : 0.0f;
+    if (FP6) {
+        // a quad of lanes = 16 consecutive columns = two chunks = 12 bytes per digit: lane pair (0, 1) / (2, 3) of the quad holds
+        // offsets 0-3 / 4-7 of a chunk, i.e. its even / odd k-slots
+        uint8_t *rbase = reinterpret_cast<uint8_t *>(p.planes) + (size_t)row * (size_t)(p.kp >> 8) * 576;
+        const int ql = tid & 3, odd = ql & 1;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx >= kvec) continue;  // (wave-uniform: kvec is a multiple of 64)
+            const float xe[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = (uint32_t)(__float2int_rn(xe[k] * sc) + 0x210);  // fields f = d + 16 (d2: the rest, signed)
+            const int cb = (4 * idx) & 255, blk = (4 * idx) >> 8;
+            uint8_t *dst = rbase + (size_t)blk * 576 + (cb >> 6) * 144 + ((cb >> 5) & 1) * 24 + ((cb >> 4) & 1) * 12 + 4 * ql;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                uint32_t code[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = d == 2 ? ((int)u[k] >> 10) : (int)((u[k] >> (5 * d)) & 31u) - 16;
+                    const int a = t < 0 ? -t : t;
+                    code[k] = (uint32_t)a | ((uint32_t)(t >> 31) & 32u);
+                }
+                // this lane's 4 fields at k-slots 2 k + odd: bits 12 k + 6 odd of the chunk's 48
+                const uint64_t part = ((uint64_t)(code[0] | (code[1] << 12) | (code[2] << 24)) | ((uint64_t)code[3] << 36)) << (6 * odd);
+                uint32_t lo = (uint32_t)part, hi = (uint32_t)(part >> 32);
+                lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]: the pair's other half
+                hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, true);
+                const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]: the other chunk
+                // 12 bytes of the quad: dword 0 = chunk 0 bits 0-31, dword 1 = chunk 0 bits 32-47 | chunk 1 bits 0-15, dword 2 = chunk 1 bits 16-47
+                const uint32_t dw = ql == 0 ? lo : ql == 1 ? (hi | (olo << 16)) : ((lo >> 16) | (hi << 16));
+                if (ql < 3) *reinterpret_cast<uint32_t *>(dst + d * 48) = dw;
+            }
+        }
+        return;
+    }
     int8_t *base = p.planes + ((size_t)(row >> 4) * NDIG * 16 + (row & 15)) * p.kp;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -740,8 +783,11 @@ __device__ __forceinline__ gh8 expand8_f16(uint32_t w, int h, uint32_t lut_hi, g
     return (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
 }
 
-template <int FMT, int TTW, int EPI = 0>
+// RT = row tiles per wave: 4 (256-row workgroups), or 5 (320-row workgroups, chain form only): a 2560-row matrix x 4096 tokens is then
+// 8 x 64 = 512 workgroups -- exactly one round of the 512 slots (two 4-wave workgroups per CU) instead of 640 in two rounds.
+template <int FMT, int TTW, int EPI = 0, int RT = 4>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_hi) {
+    static_assert(RT == 4 || EPI == 1, "the 5-tile wave exists for the chain's epilogue only");
     constexpr int WG_TOK = TTW * 16, NB = WG_TOK * 32 / 256, ROWB = 512, kBuf = WG_TOK * ROWB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -757,11 +803,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
             by = l / gx;
         }
     }
-    const uint8_t *wptr[4];
-    const uint32_t *sptr[4];
+    const uint8_t *wptr[RT];
+    const uint32_t *sptr[RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        int t = bx * 16 + rw * 4 + rt;
+    for (int rt = 0; rt < RT; ++rt) {
+        int t = bx * (4 * RT) + rw * RT + rt;
         t = t < n_tiles ? t : n_tiles - 1;
         wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
         sptr[rt] = FMT == 1 ? reinterpret_cast<const uint32_t *>(p.stiles_h) + (size_t)t * p.nblk * 64 + g * 16 + c : nullptr;
@@ -778,18 +824,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
     int boff[8];  // this lane's unit of MFMA (m, h): 8 g + ((2 m + h) ^ fswz(c))
 #pragma unroll
     for (int u = 0; u < 8; ++u) boff[u] = c * ROWB + 128 * g + ((u ^ fswz(c)) * 16);
-    gv4f acc[4][TTW];
+    gv4f acc[RT][TTW];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
-    gv4u wn[4], bn[NB];
-    uint32_t sn[4] = {0, 0, 0, 0};
+    gv4u wn[RT], bn[NB];
+    uint32_t sn[RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
+    for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]), sn[rt] = 0;
     if (FMT == 1) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) sn[rt] = sptr[rt][0];
+        for (int rt = 0; rt < RT; ++rt) sn[rt] = sptr[rt][0];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
@@ -809,17 +855,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 #pragma unroll
             for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
         }
-        gv4u wc[4];
-        uint32_t sc[4];
+        gv4u wc[RT];
+        uint32_t sc[RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) wc[rt] = wn[rt], sc[rt] = sn[rt];
+        for (int rt = 0; rt < RT; ++rt) wc[rt] = wn[rt], sc[rt] = sn[rt];
         {
             const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
+            for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
             if (FMT == 1) {
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) sn[rt] = sptr[rt][(size_t)n1 * 64];
+                for (int rt = 0; rt < RT; ++rt) sn[rt] = sptr[rt][(size_t)n1 * 64];
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 512);
@@ -828,9 +874,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                gh8 a[4];
+                gh8 a[RT];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
                     // (s, s) of this lane's 32-block 2 g + (m >> 1): low / high half of its scale dword
                     const gh2 s2 = __builtin_bit_cast(gh2, __builtin_amdgcn_perm(0u, sc[rt], (m >> 1) ? 0x03020302u : 0x01000100u));
@@ -840,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
                 for (int ct = 0; ct < TTW; ++ct) {
                     const gh8 b = *reinterpret_cast<const gh8 *>(bcur + ct * 16 * ROWB + boff[2 * m + h]);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
                 }
             }
         }
@@ -853,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
             const float is = p.inv_scale[tok0 + c];
             float val[4][4];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < 4; ++rt)  // (RT == 4 here)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
             store_wave_tiles(p, val, tok0, c, g, bx * 16 + rw * 4);
@@ -885,10 +931,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         __syncthreads();
     }
-    const int tile0 = bx * 16 + rw * 4;
-    float lng[4][4], gout[4][4];
+    const int tile0 = bx * (4 * RT) + rw * RT;
+    float lng[RT][4], gout[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         int row0 = 16 * (tile0 + rt) + 4 * g;
         row0 = row0 + 3 < p.rows ? row0 : p.rows - 4;  // (rows % 256 == 0 on this path: never taken)
         const float4 lg = p.stats_in ? *reinterpret_cast<const float4 *>(p.ln_g + row0) : float4{0.f, 0.f, 0.f, 0.f};
@@ -901,15 +947,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
     for (int tt = 0; tt < TTW; ++tt) {
         const int tok0 = (by * TTW + tt) * 16, token = tok0 + c;
         const bool live = token < p.m;
-        float val[4][4];
+        float val[RT][4];
         float2 mr = float2{0.f, 1.f};
         if (p.stats_in) mr = mu_rs[tt * 16 + c];
         const float is = p.inv_scale ? p.inv_scale[token] : 1.0f;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[rt][j] = (acc[rt][tt][j] * is - mr.x * lng[rt][j]) * mr.y;
-        if (p.silu_mul) {
+        if (RT == 4 && p.silu_mul) {
             // row tiles alternate (gate, up): FeedForward::forward T:756-781; the product goes out as f16 rows for the down-projection
             const int half_rows = p.rows >> 1, ra = 16 * (tile0 >> 1) + 4 * g;
 #pragma unroll
@@ -934,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             const int row0 = 16 * (tile0 + rt) + 4 * g;
             const size_t off = (size_t)(live ? token : 0) * p.rows + row0;
             if (p.residual) {  // x = x + W h (in place: y aliases the residual), T:1073
@@ -953,10 +999,169 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
                 }
             }
         }
-        if (p.stats_out) {  // this wave's 64 rows of the token: the consumer's LayerNorm adds the slabs up
+        if (p.stats_out) {  // this wave's 16 RT rows of the token: the consumer's LayerNorm adds the slabs up
             s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
             s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
             if (g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(bx * 4 + rw) * p.stats_stride + token)) = live ? float2{s1, s2} : float2{0.f, 0.f};
+            // RT == 5: rows / 80 partials fill the first slabs of the [rows / 64] array the interface names; the workgroups' first waves
+            // clear the rows / 320 surplus ones (4 gx + bx), so the consumer still adds rows / 64 entries up
+            if (RT == 5 && rw == 0 && g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(4 * gridDim.x + bx) * p.stats_stride + token)) = float2{0.f, 0.f};
+        }
+    }
+}
+
+// ================================================================================================================================
+// k_gemm_fp6: the 2-digit form's arithmetic on the block-scaled fp6 x fp4 matrix instruction (round 4).
+// v_mfma_scale_f32_16x16x128_f8f6f4 with A = fp4 (e2m1: every value of a code map in -2 .. 2 is exact) and B = fp6 (e2m3: n / 8 is
+// exact for |n| <= 16, a balanced base-32 digit) multiplies K = 128 in the cycles the int8 form needs for K = 64, and its E8M0 block
+// scales are free powers of two: the three digits of q = d0 + 32 d1 + 1024 d2 enter with scales 2^3, 2^8, 2^13 (the 2^3 undoes the
+// n / 8) and accumulate into ONE f32 accumulator -- every product and every partial sum is an integer, exact in f32 while it stays
+// below 2^24 (|w q| <= 2^15 per term: a sum only leaves that range when more than 512 terms line up at full scale; past it the
+// accumulator rounds like any f32 sum, 2^-24 relative).  So this form computes the SAME integer as k_gemm_mfma<2, ...> from the SAME
+// quantised q (k_quant_rows<2, NV, 1>) with 3 MFMAs per 128 columns instead of 4, half the accumulator registers, and multipliers a
+// fraction of the int8 ones' size (the int8 loop runs at a power limit: DESIGN 4.5; tools/probes/mfma_fp6_probe.hip).
+// Operands: lane (row r, group g) of a streaming tile holds the 64 codes of columns 64 g .. 64 g + 63; MFMA m = 0, 1 takes dwords
+// 2 m, 2 m + 1 expanded to 32 fp4 nibbles (expand16_fp4: k-slot 8 q + n = column 64 g + 32 m + 8 q + 4 (n & 1) + (n >> 1)); the
+// B operand of lane (token c, group g) is the 24 bytes the quantiser wrote for (g, digit, m) in that slot order.
+// Activation tile in LDS: [g 4][token 16 TTW][144 bytes = digit 3 x m 2 x 24]: a lane's nine 16-byte units are contiguous, and the
+// sixteen lanes of every ds_read_b128 service group (MI355X_MICROARCH.md, LDS: all 16 tokens, mixed g) touch units 9 c + const
+// (mod 16): sixteen different ones, since 9 is odd and a group's slab is a multiple of 16 units -- conflict-free without padding.
+typedef int gv8i __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void expand16_fp4(uint32_t w, uint32_t lut4, int &o0, int &o1) {
+    const uint32_t p0 = __builtin_amdgcn_perm(0u, lut4, w & 0x03030303u), p1 = __builtin_amdgcn_perm(0u, lut4, (w >> 2) & 0x03030303u);
+    const uint32_t p2 = __builtin_amdgcn_perm(0u, lut4, (w >> 4) & 0x03030303u), p3 = __builtin_amdgcn_perm(0u, lut4, (w >> 6) & 0x03030303u);
+    o0 = (int)((p1 << 4) | p0);  // byte b: low nibble = element b, high nibble = element 4 + b of the dword's sixteen
+    o1 = (int)((p3 << 4) | p2);  //         elements 8 + b, 12 + b
+}
+
+// RT = row tiles per wave: 4, or 5 (320-row workgroups: gemm_five_tiles; no silu * mul pairing with it).
+template <int TTW, int RT = 4>
+__global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {
+    constexpr int T = 16 * TTW, UNITS = T * 36, NB = (UNITS + 255) / 256, kBuf = T * 576;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4, rw = wave;
+    const int n_tiles = (p.rows + 15) >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {  // one XCD works through consecutive logical ids (k_gemm_mfma explains)
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if ((total & 7) == 0) {
+            const int l = (id & 7) * (total >> 3) + (id >> 3);
+            bx = l % gx;
+            by = l / gx;
+        }
+    }
+    const uint8_t *wptr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int t = bx * (4 * RT) + rw * RT + rt;
+        t = t < n_tiles ? t : n_tiles - 1;
+        wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
+    }
+    // this thread's 16-byte units of the activation tile: unit u of a token's 576 bytes = (g = u / 9, k = u % 9)
+    const size_t row_bytes = (size_t)p.nblk * 576;
+    const uint8_t *bsrc[NB];
+    int bdst[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int idx = tid + 256 * i;
+        idx = idx < UNITS ? idx : UNITS - 1;  // (surplus threads of the last round repeat its last unit: same bytes, same place)
+        const int tok = idx / 36, u = idx % 36, gg = u / 9, k = u % 9;
+        bsrc[i] = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)(by * T + tok) * row_bytes + u * 16;
+        bdst[i] = ((gg * T + tok) * 9 + k) * 16;
+    }
+    gv4f acc[RT][TTW];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
+    gv4u wn[RT], bn[NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+    {
+        const int n1 = p.nblk > 1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 576);
+    }
+    __syncthreads();
+    const int bread = (g * T + c) * 144;
+
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        const uint8_t *bcur = lds + (blk & 1) * kBuf + bread;
+        uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
+        if (blk + 1 < p.nblk) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
+        }
+        gv4u wc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) wc[rt] = wn[rt];
+        {
+            const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 576);
+        }
+        v4i a[2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            int e[8];
+            expand16_fp4(wc[rt].x, lut4, e[0], e[1]);
+            expand16_fp4(wc[rt].y, lut4, e[2], e[3]);
+            expand16_fp4(wc[rt].z, lut4, e[4], e[5]);
+            expand16_fp4(wc[rt].w, lut4, e[6], e[7]);
+            a[0][rt] = (v4i){e[0], e[1], e[2], e[3]};
+            a[1][rt] = (v4i){e[4], e[5], e[6], e[7]};
+        }
+#pragma unroll
+        for (int ct = 0; ct < TTW; ++ct) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const uint8_t *bp = bcur + ct * 16 * 144 + d * 48;
+                const v4i r0 = *reinterpret_cast<const v4i *>(bp), r1 = *reinterpret_cast<const v4i *>(bp + 16), r2 = *reinterpret_cast<const v4i *>(bp + 32);
+                const gv8i b0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1);
+                const gv8i b1 = __builtin_shufflevector(r1, r2, 2, 3, 4, 5, 6, 7, -1, -1);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[0][rt], a[0][rt], 0, 1, 2, 3, -1, -1, -1, -1), b0, acc[rt][ct], 4, 2,
+                                                                                   0, 127, 0, 130 + 5 * d);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[1][rt], a[1][rt], 0, 1, 2, 3, -1, -1, -1, -1), b1, acc[rt][ct], 4, 2,
+                                                                                   0, 127, 0, 130 + 5 * d);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        const int tok0 = (by * TTW + tt) * 16;
+        const float is = p.inv_scale[tok0 + c];  // (padding rows: 0)
+        float val[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[rt][j] = acc[rt][tt][j] * is;
+        store_wave_tiles(p, val, tok0, c, g, bx * (4 * RT) + rw * RT);
+        if (RT == 5) {  // the fifth tile: 64 contiguous bytes per token
+            const int token = tok0 + c, row0 = 16 * (bx * 20 + rw * 5 + 4) + 4 * g;
+            if (token < p.m && row0 + 3 < p.rows) {
+                const size_t off = (size_t)token * p.rows + row0;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[4][tt][j] * is;
+                if (p.residual) {
+                    const float4 r = *reinterpret_cast<const float4 *>(p.residual + off);
+                    o[0] += r.x, o[1] += r.y, o[2] += r.z, o[3] += r.w;
+                }
+                store_out4(p.y + off, o[0], o[1], o[2], o[3]);
+            }
         }
     }
 }
@@ -1012,6 +1217,14 @@ static int gemm_token_tiles(size_t gx0, size_t m_pad, bool tail_rule) {
     }
     return ttw;
 }
+// Five row tiles per wave (320-row workgroups of 64 tokens) instead of four, for the forms whose accumulators leave the registers
+// (f32 accumulators: the f16 chain, the fp6 form): taken when it needs fewer workgroup rounds x rows per workgroup on the 512 slots.
+// 2560 output rows x 4096 tokens: 640 workgroups of 256 rows = two rounds (cost 2 x 4), 512 of 320 rows = exactly one (cost 5).
+static bool gemm_five_tiles(size_t rows, size_t m_pad) {
+    if (rows % 320 != 0) return false;
+    const size_t slots = 2 * kGemmCUs, tb = m_pad / 64;
+    return div_ceil(rows / 320 * tb, slots) * 5 < div_ceil(div_ceil(rows, 256) * tb, slots) * 4;
+}
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -1028,7 +1241,8 @@ bool gemm_supported(const Weights &w) {
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig) {
     const size_t wg_tokens = 128, m_pad = div_ceil(m, wg_tokens) * wg_tokens;
     const size_t kp = div_ceil(cols, 256) * 256;
-    return m_pad * ndig * kp + div_ceil(m_pad * sizeof(float), 256) * 256 + 256;
+    const size_t plane_bytes = ndig == 2 ? kp / 256 * 576 : ndig * kp;  // 2 digits: room for the fp6 form's three base-32 digits (k_gemm_fp6)
+    return m_pad * plane_bytes + div_ceil(m_pad * sizeof(float), 256) * 256 + 256;
 }
 
 template <int NDIG, int TTW>
@@ -1126,6 +1340,47 @@ static hipError_t launch_gemm_f16(const Weights &w, const QuantArgs &q, const Ge
     return hipGetLastError();
 }
 
+// the fp6 form (k_gemm_fp6) takes unscaled matrices whose code map fits fp4 (every map of the reference: values in -2 .. 2)
+static uint32_t lut_fp4(uint32_t lut) {
+    uint32_t out = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int v = (int)(int8_t)((lut >> (8 * c)) & 0xffu);
+        const uint32_t nib = v == 0 ? 0x0u : v == 1 ? 0x2u : v == -1 ? 0xAu : v == 2 ? 0x4u : 0xCu;  // e2m1: 1.0 = 0b0010, 2.0 = 0b0100
+        out |= nib << (8 * c);
+    }
+    return out;
+}
+int gemm_fp6_mode() {
+    static const int mode = [] { const char *e = getenv("BITNET_HIP_GEMM_FP6"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+static bool gemm_fp6_takes(const Weights &w, int ndig) { return gemm_fp6_mode() && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 4 == 0; }
+
+static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
+    const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
+    void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<2, 3, 1> : k_quant_rows<2, 8, 1>;
+    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
+    size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
+    int ttw = gemm_token_tiles(gx0, q.m_pad, false);
+    const bool rt5 = ttw == 4 && !a.silu_mul && w.rows % 4 == 0 && gemm_five_tiles(w.rows, q.m_pad);
+    if (rt5) gx0 = w.rows / 320;
+    else ttw = gemm_token_tiles(gx0, q.m_pad, true);
+    void (*fk)(GemmArgs, uint32_t) = rt5 ? k_gemm_fp6<4, 5> : ttw == 4 ? k_gemm_fp6<4> : ttw == 2 ? k_gemm_fp6<2> : k_gemm_fp6<1>;
+    {
+        static std::mutex f_mu;
+        static std::unordered_set<const void *> f_raised;
+        std::lock_guard<std::mutex> lk(f_mu);
+        if (!f_raised.count((const void *)fk)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            f_raised.insert((const void *)fk);
+        }
+    }
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 6, rt5 ? 80 : 64};
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, a, lut_fp4(w.lut));
+    return hipGetLastError();
+}
+
 // ---- the f16 activation chain: every projection input is an f16 matrix its PRODUCER wrote (no quantiser kernel between the launches) ----
 bool gemm_f16_chain_supported(const Weights &w) {
     if (!w.tiles || w.cols % 256 != 0 || w.rows % 256 != 0 || w.cols > 8192) return false;
@@ -1169,11 +1424,14 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     a.yh = static_cast<_Float16 *>(io.yh);
     a.gamma_out = io.gamma_out;
     a.stats_out = io.stats_out;
-    const size_t gx0 = w.rows / 256;
+    size_t gx0 = w.rows / 256;
     const int ttw = gemm_token_tiles(gx0, m_pad, false);
     const bool fmt1 = w.scaled;
-    void (*fk)(GemmArgs, uint32_t) = fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4, 1> : ttw == 2 ? k_gemm_f16a<1, 2, 1> : k_gemm_f16a<1, 1, 1>)
-                                          : (ttw == 4 ? k_gemm_f16a<0, 4, 1> : ttw == 2 ? k_gemm_f16a<0, 2, 1> : k_gemm_f16a<0, 1, 1>);
+    const bool rt5 = ttw == 4 && !io.silu_mul && gemm_five_tiles(w.rows, m_pad);
+    if (rt5) gx0 = w.rows / 320;
+    void (*fk)(GemmArgs, uint32_t) = rt5    ? (fmt1 ? k_gemm_f16a<1, 4, 1, 5> : k_gemm_f16a<0, 4, 1, 5>)
+                                     : fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4, 1> : ttw == 2 ? k_gemm_f16a<1, 2, 1> : k_gemm_f16a<1, 1, 1>)
+                                            : (ttw == 4 ? k_gemm_f16a<0, 4, 1> : ttw == 2 ? k_gemm_f16a<0, 2, 1> : k_gemm_f16a<0, 1, 1>);
     {
         static std::mutex f_mu;
         static std::unordered_set<const void *> f_raised;
@@ -1184,7 +1442,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
             f_raised.insert((const void *)fk);
         }
     }
-    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5};
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5, rt5 ? 80 : 64};
     const size_t lds = (size_t)2 * ttw * 16 * 512;  // (the epilogue's 5 KiB of statistics scratch fit the smallest tile pair: 16 KiB)
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
@@ -1225,17 +1483,19 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
+    const bool takes_f16 = !fu.int8_form && ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite;
     if (fu.x_f16 || fu.y_f16) {  // f16 hand-over: the int8 digit form's quantiser reads f16 rows; silu * up goes out as f16 rows
-        const bool f16_form = (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite);
+        const bool f16_form = takes_f16;
         if (f16_form || (fu.y_f16 && (!fu.silu_mul || ((w.rows >> 1) & 3) != 0))) return hipErrorInvalidValue;
         if (fu.y_f16) a.yh = reinterpret_cast<_Float16 *>(y), a.y = nullptr;
     }
-    if (ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite) return launch_gemm_f16(w, q, a, stream);
-    {
+    if (takes_f16) return launch_gemm_f16(w, q, a, stream);  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
+    if (!fu.int8_form) {
         static const int f16a_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16A"); return e ? atoi(e) : 0; }();
         if (f16a_mode && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 256 == 0)
             return launch_gemm_f16(w, q, a, stream);
-    }  // BitNet32-F16 at f16 activation precision: the f16 matrix cores
+        if (gemm_fp6_takes(w, ndig)) return launch_gemm_fp6(w, q, a, stream);  // unscaled matrices at 2 digits: the same integer on the fp6 x fp4 MFMA
+    }
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);
     return launch_gemm_t<4, 2>(w, q, a, stream);

@@ -218,9 +218,14 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
  * The int8 digit planes live in a caller-owned device workspace.
  * flags (beside BITNET_HIP_FUSE_SILU_MUL), int8 digit form only -- f16 hand-over between the prompt forward's launches:
  *   BITNET_HIP_FUSE_X_F16: x_dev holds f16 rows [m][cols] (the attention's f16 output, the f16 silu * up rows); no LayerNorm with it
- *   BITNET_HIP_FUSE_Y_F16: with FUSE_SILU_MUL, y_dev receives the product as f16 rows [m][rows / 2] */
+ *   BITNET_HIP_FUSE_Y_F16: with FUSE_SILU_MUL, y_dev receives the product as f16 rows [m][rows / 2]
+ *   BITNET_HIP_FUSE_INT8_DIGITS: keep the int8 base-256 digit planes at digits = 2 as well.  Without it digits = 2 picks the fastest
+ *     form the matrix admits: BitNet32-F16 -> f16 activations on the f16 matrix cores (above); unscaled matrices (QK256) -> the SAME
+ *     15-bit integer per activation as three base-32 digits on the block-scaled fp6 x fp4 MFMA (k_gemm_fp6: same products, f32
+ *     accumulation of exact integers, bit-identical to the int8 form while every partial sum stays below 2^24) */
 #define BITNET_HIP_FUSE_X_F16 2
 #define BITNET_HIP_FUSE_Y_F16 4
+#define BITNET_HIP_FUSE_INT8_DIGITS 8
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
 int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
