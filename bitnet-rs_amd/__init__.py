@@ -142,6 +142,7 @@ class HipLib:
         L.bitnet_hip_matmul_workspace_bytes.restype = _sz
         L.bitnet_hip_matmul_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp, _sz, _vp]
         L.bitnet_hip_matmul_last_tile.argtypes = [C.POINTER(C.c_int)] * 4
+        L.bitnet_hip_matmul_last_wave_rows.argtypes = []
         L.bitnet_hip_weights_bind_ln.argtypes = [C.c_uint64, _vp, _vp]
         L.bitnet_hip_weights_concat.argtypes = [C.POINTER(C.c_uint64), _sz, C.c_int, C.POINTER(C.c_uint64)]
         L.bitnet_hip_gemv_fused_dev.argtypes = [C.c_uint64, _vp, _vp, _sz, _vp, C.c_float, _vp, C.c_int, _vp]
@@ -351,6 +352,10 @@ class HipLib:
         v = [C.c_int() for _ in range(4)]
         self._check(self.c.bitnet_hip_matmul_last_tile(*[C.byref(x) for x in v]))
         return dict(zip(("digits", "wave_tokens", "waves", "scale_mode"), (x.value for x in v)))
+
+    def matmul_last_wave_rows(self) -> int:
+        """Output rows per wave of this thread's last tiled matmul: 64, or 80 (320-row workgroups)."""
+        return int(self.c.bitnet_hip_matmul_last_wave_rows())
 
     def attention_prefill_workspace_bytes(self, n_heads: int, n_kv: int, seq_len: int) -> int:
         return int(self.c.bitnet_hip_attention_prefill_workspace_bytes(n_heads, n_kv, seq_len))

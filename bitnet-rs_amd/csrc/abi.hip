@@ -497,6 +497,9 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     fu.x_f16 = (flags & BITNET_HIP_FUSE_X_F16) != 0;
     fu.y_f16 = (flags & BITNET_HIP_FUSE_Y_F16) != 0;
     fu.int8_form = (flags & BITNET_HIP_FUSE_INT8_DIGITS) != 0;
+    fu.fp6_form = (flags & BITNET_HIP_FUSE_FP6_DIGITS) != 0;
+    if (fu.fp6_form && (fu.int8_form || digits != 2 || !gemm_fp6_supported(*w)))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_FP6_DIGITS needs digits = 2, an unscaled matrix with a code map in -2..2, and no FUSE_INT8_DIGITS");
     if (fu.silu_mul && (!w->paired || residual_dev))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT,
                          "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
@@ -573,6 +576,8 @@ int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *
     if (scale_mode) *scale_mode = t.scale_mode;
     return t.digits ? BITNET_HIP_OK : set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "no tiled matmul has been launched on this thread");
 }
+
+int bitnet_hip_matmul_last_wave_rows(void) { return g_last_gemm_tile.digits ? g_last_gemm_tile.wave_rows : 0; }
 
 int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m,
                               const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags,

@@ -95,6 +95,7 @@ struct GemvFusion {
     bool silu_mul = false;            // rows are (gate tile, up tile) pairs: y = silu(gate) * up
     bool x_f16 = false, y_f16 = false;  // prefill matmul only: x rows / the silu * up output are f16 (BITNET_HIP_FUSE_X_F16 / _Y_F16)
     bool int8_form = false;             // prefill matmul only: keep the int8 digit planes (BITNET_HIP_FUSE_INT8_DIGITS: no fp6 / f16 form)
+    bool fp6_form = false;              // prefill matmul only: the fp6 x fp4 form of the 2-digit product (BITNET_HIP_FUSE_FP6_DIGITS)
     // x = the decode attention's output, merged from its chunk records by the GEMV itself (no combine launch):
     // records of launch_attn_decode(..., combine = false); contexts of at most 4 records
     const float *attn_rec = nullptr;
@@ -166,6 +167,7 @@ struct ReferencePin {
 size_t weights_device_bytes(const Weights &w);
 // many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
 bool gemm_supported(const Weights &w);
+bool gemm_fp6_supported(const Weights &w);  // unscaled, code map in -2 .. 2: the fp6 x fp4 form of the 2-digit product (k_gemm_fp6)
 bool gemm_needs_row_major_scales(const Weights &w);  // 256-block scales and non-f16 32-block scales: the others read the scale tiles
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);
 // The f16 activation chain of the prompt forward (kernels_gemm.hip k_gemm_f16a<.., 1>): the input is an f16 matrix [m_pad][cols]

@@ -164,40 +164,51 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
     const float inv_s = __uint_as_float((uint32_t)(be - S) << 23);        // 2^(E - S)
     if (tid == 0) p.inv_scale[row] = live ? inv_s : 0.0f;
     if (FP6) {
-        // a quad of lanes = 16 consecutive columns = two chunks = 12 bytes per digit: lane pair (0, 1) / (2, 3) of the quad holds
-        // offsets 0-3 / 4-7 of a chunk, i.e. its even / odd k-slots
-        uint8_t *rbase = reinterpret_cast<uint8_t *>(p.planes) + (size_t)row * (size_t)(p.kp >> 8) * 576;
-        const int ql = tid & 3, odd = ql & 1;
+        // q = rint(x 2^(S - E)) as f32 goes through LDS so that ONE lane owns the 32 columns of an MFMA operand (lane group g, MFMA m
+        // of a 256-block): columns 32 u .. 32 u + 31 live in units 9 u .. 9 u + 7 of 16 bytes (the ninth unit of every 144 bytes is
+        // padding: with it the sixteen lanes of a ds_read_b128 service group touch sixteen different units)
+        extern __shared__ __attribute__((aligned(16))) float qrow[];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
-            if (idx >= kvec) continue;  // (wave-uniform: kvec is a multiple of 64)
-            const float xe[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            uint32_t u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = (uint32_t)(__float2int_rn(xe[k] * sc) + 0x210);  // fields f = d + 16 (d2: the rest, signed)
-            const int cb = (4 * idx) & 255, blk = (4 * idx) >> 8;
-            uint8_t *dst = rbase + (size_t)blk * 576 + (cb >> 6) * 144 + ((cb >> 5) & 1) * 24 + ((cb >> 4) & 1) * 12 + 4 * ql;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                uint32_t code[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = d == 2 ? ((int)u[k] >> 10) : (int)((u[k] >> (5 * d)) & 31u) - 16;
-                    const int a = t < 0 ? -t : t;
-                    code[k] = (uint32_t)a | ((uint32_t)(t >> 31) & 32u);
-                }
-                // this lane's 4 fields at k-slots 2 k + odd: bits 12 k + 6 odd of the chunk's 48
-                const uint64_t part = ((uint64_t)(code[0] | (code[1] << 12) | (code[2] << 24)) | ((uint64_t)code[3] << 36)) << (6 * odd);
-                uint32_t lo = (uint32_t)part, hi = (uint32_t)(part >> 32);
-                lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]: the pair's other half
-                hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, true);
-                const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]: the other chunk
-                // 12 bytes of the quad: dword 0 = chunk 0 bits 0-31, dword 1 = chunk 0 bits 32-47 | chunk 1 bits 0-15, dword 2 = chunk 1 bits 16-47
-                const uint32_t dw = ql == 0 ? lo : ql == 1 ? (hi | (olo << 16)) : ((lo >> 16) | (hi << 16));
-                if (ql < 3) *reinterpret_cast<uint32_t *>(dst + d * 48) = dw;
-            }
+            if (idx >= kvec) continue;
+            *reinterpret_cast<float4 *>(qrow + ((idx >> 3) * 9 + (idx & 7)) * 4) =
+                float4{__builtin_rintf(v[i].x * sc), __builtin_rintf(v[i].y * sc), __builtin_rintf(v[i].z * sc), __builtin_rintf(v[i].w * sc)};
         }
+        __syncthreads();
+        // balanced base-32 digits in f32: r1 = rint(q / 32), d0 = q - 32 r1 (|d0| <= 16: a tie rounds to even, +-16 is an fp6 value),
+        // likewise d1 from r1, d2 = rint(r1 / 32) (|d2| <= 16 since |q| <= 2^14).  v_cvt_scalef32_2xpk16_fp6_f32 packs 32 values / 8 into
+        // 24 bytes, k-slot 2 i from its first operand's element i and 2 i + 1 from its second's (tools/probes/cvt_fp6_probe.hip): with
+        // first = columns 8 q + 0 .. 3, second = columns 8 q + 4 .. 7 that IS the slot order of expand16_fp4's nibbles
+        typedef float qv16f __attribute__((ext_vector_type(16)));
+        typedef unsigned qv6u __attribute__((ext_vector_type(6)));
+        uint8_t *rbase = reinterpret_cast<uint8_t *>(p.planes) + (size_t)row * (size_t)(p.kp >> 8) * 576;
+        uint8_t *orow = reinterpret_cast<uint8_t *>(qrow) + (size_t)(p.kp >> 5) * 144;
+        // one work item = (digit, 32-column unit): all four waves pack (80 units x 3 digits for 2560 columns)
+        const int n_units = p.kp >> 5;
+        for (int w = tid; w < 3 * n_units; w += 256) {
+            const int d = w / n_units, u = w - d * n_units;
+            qv16f lo, hi;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 f = *reinterpret_cast<const float4 *>(qrow + (u * 9 + k) * 4);
+                const float xs[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r1 = __builtin_rintf(xs[e] * 0.03125f), d0 = __builtin_fmaf(r1, -32.0f, xs[e]);
+                    const float r2 = __builtin_rintf(r1 * 0.03125f), d1 = __builtin_fmaf(r2, -32.0f, r1);
+                    const float dv = d == 0 ? d0 : d == 1 ? d1 : r2;
+                    if (k & 1) hi[4 * (k >> 1) + e] = dv;
+                    else lo[4 * (k >> 1) + e] = dv;
+                }
+            }
+            const qv6u r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo, hi, 8.0f);
+            // the packed row is assembled in LDS (behind the integers) and leaves in whole 16-byte pieces, lane after lane
+            uint2 *o = reinterpret_cast<uint2 *>(orow + (size_t)(u >> 3) * 576 + ((u >> 1) & 3) * 144 + (u & 1) * 24 + d * 48);
+            o[0] = uint2{r[0], r[1]}, o[1] = uint2{r[2], r[3]}, o[2] = uint2{r[4], r[5]};
+        }
+        __syncthreads();
+        for (int i = tid; i < (p.kp >> 8) * 36; i += 256) reinterpret_cast<uint4 *>(rbase)[i] = reinterpret_cast<const uint4 *>(orow)[i];
         return;
     }
     int8_t *base = p.planes + ((size_t)(row >> 4) * NDIG * 16 + (row & 15)) * p.kp;
@@ -1108,6 +1119,16 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 576);
         }
+        // B operands one group (token tile, digit) ahead of their MFMAs: hipcc otherwise waits for every group's reads right after
+        // issuing them; group 0 is requested ahead of the code expansion
+        // (the wide tile only: the 5-tile and the narrow forms have no registers to spare for the second operand set)
+        constexpr int NG = TTW * 3;
+        constexpr bool PIPE = TTW == 4 && RT == 4;
+        v4i rr[2][3];
+        if (PIPE) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rr[0][q] = *reinterpret_cast<const v4i *>(bcur + 16 * q);
+        }
         v4i a[2][RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1120,22 +1141,30 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
             a[1][rt] = (v4i){e[4], e[5], e[6], e[7]};
         }
 #pragma unroll
-        for (int ct = 0; ct < TTW; ++ct) {
+        for (int grp = 0; grp < NG; ++grp) {
+            const int ct = grp / 3, d = grp % 3;
+            if (PIPE && grp + 1 < NG) {
+                const uint8_t *bp = bcur + ((grp + 1) / 3) * 16 * 144 + ((grp + 1) % 3) * 48;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const uint8_t *bp = bcur + ct * 16 * 144 + d * 48;
-                const v4i r0 = *reinterpret_cast<const v4i *>(bp), r1 = *reinterpret_cast<const v4i *>(bp + 16), r2 = *reinterpret_cast<const v4i *>(bp + 32);
-                const gv8i b0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1);
-                const gv8i b1 = __builtin_shufflevector(r1, r2, 2, 3, 4, 5, 6, 7, -1, -1);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[0][rt], a[0][rt], 0, 1, 2, 3, -1, -1, -1, -1), b0, acc[rt][ct], 4, 2,
-                                                                                   0, 127, 0, 130 + 5 * d);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[1][rt], a[1][rt], 0, 1, 2, 3, -1, -1, -1, -1), b1, acc[rt][ct], 4, 2,
-                                                                                   0, 127, 0, 130 + 5 * d);
+                for (int q = 0; q < 3; ++q) rr[(grp + 1) & 1][q] = *reinterpret_cast<const v4i *>(bp + 16 * q);
             }
+            if (!PIPE) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rr[grp & 1][q] = *reinterpret_cast<const v4i *>(bcur + ct * 16 * 144 + d * 48 + 16 * q);
+            }
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            const v4i r0 = rr[grp & 1][0], r1 = rr[grp & 1][1], r2 = rr[grp & 1][2];
+            const gv8i b0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1);
+            const gv8i b1 = __builtin_shufflevector(r1, r2, 2, 3, 4, 5, 6, 7, -1, -1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[0][rt], a[0][rt], 0, 1, 2, 3, -1, -1, -1, -1), b0, acc[rt][ct], 4, 2, 0,
+                                                                               127, 0, 130 + 5 * d);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[1][rt], a[1][rt], 0, 1, 2, 3, -1, -1, -1, -1), b1, acc[rt][ct], 4, 2, 0,
+                                                                               127, 0, 130 + 5 * d);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -1354,12 +1383,12 @@ int gemm_fp6_mode() {
     static const int mode = [] { const char *e = getenv("BITNET_HIP_GEMM_FP6"); return e ? atoi(e) : 0; }();
     return mode;
 }
-static bool gemm_fp6_takes(const Weights &w, int ndig) { return gemm_fp6_mode() && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 4 == 0; }
+bool gemm_fp6_supported(const Weights &w) { return gemm_supported(w) && !w.scaled && lut_fits_f16w(w.lut); }
 
 static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
     const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<2, 3, 1> : k_quant_rows<2, 8, 1>;
-    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
+    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), (size_t)(q.kp / 32) * 144 + (size_t)(q.kp / 256) * 576, stream, q);  // LDS: the row's integers (144 bytes per 32 columns) + its packed image
     size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
     int ttw = gemm_token_tiles(gx0, q.m_pad, false);
     const bool rt5 = ttw == 4 && !a.silu_mul && w.rows % 4 == 0 && gemm_five_tiles(w.rows, q.m_pad);
@@ -1451,6 +1480,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
 hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,
                             void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!gemm_supported(w) || (ndig != 2 && ndig != 3 && ndig != 4)) return hipErrorInvalidValue;
+    if (fu.fp6_form && (fu.int8_form || ndig != 2 || !gemm_fp6_supported(w))) return hipErrorInvalidValue;
     if (workspace_bytes < gemm_workspace_bytes(m, w.cols, ndig) || !workspace) return hipErrorInvalidValue;
     const bool k32 = gemm_k32(w);
     const int ws_mode = !w.scaled ? 0 : w.block_size == 32 ? 2 : 1;
@@ -1494,7 +1524,8 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
         static const int f16a_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16A"); return e ? atoi(e) : 0; }();
         if (f16a_mode && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 256 == 0)
             return launch_gemm_f16(w, q, a, stream);
-        if (gemm_fp6_takes(w, ndig)) return launch_gemm_fp6(w, q, a, stream);  // unscaled matrices at 2 digits: the same integer on the fp6 x fp4 MFMA
+        // unscaled matrices at 2 digits: the same integer on the fp6 x fp4 MFMA, on request (flag) or by BITNET_HIP_GEMM_FP6=1
+        if (ndig == 2 && (fu.fp6_form || gemm_fp6_mode()) && gemm_fp6_supported(w)) return launch_gemm_fp6(w, q, a, stream);
     }
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);

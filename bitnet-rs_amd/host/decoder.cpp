@@ -752,6 +752,15 @@ bool Decoder::handover16_applies(int digits) const {
     return c_.ffn % 4 == 0;
 }
 
+// (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections)
+bool Decoder::hybrid_applies() const {
+    static const bool hybrid_env = !(getenv("BITNET_HOST_PREFILL_HYBRID") && atoi(getenv("BITNET_HOST_PREFILL_HYBRID")) == 0);
+    if (!hybrid_env || layers_.empty()) return false;
+    for (const auto &L : layers_)
+        if (bitnet_hip_matmul_f16_supported(L.o) != 1 || bitnet_hip_matmul_f16_supported(L.down) != 1) return false;
+    return true;
+}
+
 int Decoder::ensure_chain_buffers(size_t N) {
     const size_t H = c_.hidden, QD = (size_t)c_.n_heads * c_.head_dim, F = c_.ffn;
     const size_t NP = (N + 63) / 64 * 64, nst = H / 64;
@@ -858,6 +867,10 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         const int rc = ensure_chain_buffers(N);
         if (rc) return rc;
     }
+    // Hybrid (unscaled matrices): the two projections whose inputs ARE f16 rows (the attention output, silu * up) multiply them on the f16
+    // matrix cores as they stand (k_gemm_f16a, 320-row workgroups: one round of the chip at 4096 tokens) -- no quantiser launch, no second
+    // rounding of values that were rounded to f16 already; q|k|v and gate|up keep the faster int8 digit planes behind their LayerNorm.
+    const bool hybrid = h16 && hybrid_applies();
     for (auto &L : layers_) {
         if (chain) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
@@ -865,10 +878,16 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
             BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,
                                                         (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_atth_,
                                                         (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | BITNET_HIP_ATTN_OUT_F16, s));
-            BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+            if (hybrid)
+                BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
+            else
+                BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, (float *)pf_hh_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | BITNET_HIP_FUSE_Y_F16, digits,
                                              pf_gemm_ws_, pf_gemm_ws_bytes_, s));
-            BCHK(bitnet_hip_matmul_fused_dev(L.down, (const float *)pf_hh_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+            if (hybrid)
+                BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
+            else
+                BCHK(bitnet_hip_matmul_fused_dev(L.down, (const float *)pf_hh_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             continue;
         }
         if (kv_f16_)
@@ -1018,6 +1037,7 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
         if (rc) return rc;
     }
     float *att_out = h16 ? static_cast<float *>(pf_atth_) : pf_att_;
+    const bool hybrid = h16 && hybrid_applies();  // o / down on the f16 matrix cores, as in the unsharded prefill
     const int aflags = (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | (h16 ? BITNET_HIP_ATTN_OUT_F16 : 0);
     for (auto &L : layers_) {
         HCHK(mark(0, s));
@@ -1054,10 +1074,16 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
         HCHK(mark(4, s));
         const int xf = h16 ? BITNET_HIP_FUSE_X_F16 : 0, yf = h16 ? BITNET_HIP_FUSE_Y_F16 : 0;
         float *h_buf = h16 ? static_cast<float *>(pf_hh_) : pf_h_;
-        BCHK(bitnet_hip_matmul_fused_dev(L.o, att_out, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        if (hybrid)
+            BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
+        else
+            BCHK(bitnet_hip_matmul_fused_dev(L.o, att_out, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, h_buf, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | yf, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
-        BCHK(bitnet_hip_matmul_fused_dev(L.down, h_buf, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        if (hybrid)
+            BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
+        else
+            BCHK(bitnet_hip_matmul_fused_dev(L.down, h_buf, pf_x_, N, nullptr, 0.f, pf_x_, xf, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         HCHK(mark(5, s));
         ++li;
     }

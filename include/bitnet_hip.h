@@ -219,13 +219,17 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
  * flags (beside BITNET_HIP_FUSE_SILU_MUL), int8 digit form only -- f16 hand-over between the prompt forward's launches:
  *   BITNET_HIP_FUSE_X_F16: x_dev holds f16 rows [m][cols] (the attention's f16 output, the f16 silu * up rows); no LayerNorm with it
  *   BITNET_HIP_FUSE_Y_F16: with FUSE_SILU_MUL, y_dev receives the product as f16 rows [m][rows / 2]
- *   BITNET_HIP_FUSE_INT8_DIGITS: keep the int8 base-256 digit planes at digits = 2 as well.  Without it digits = 2 picks the fastest
- *     form the matrix admits: BitNet32-F16 -> f16 activations on the f16 matrix cores (above); unscaled matrices (QK256) -> the SAME
- *     15-bit integer per activation as three base-32 digits on the block-scaled fp6 x fp4 MFMA (k_gemm_fp6: same products, f32
- *     accumulation of exact integers, bit-identical to the int8 form while every partial sum stays below 2^24) */
+ *   BITNET_HIP_FUSE_INT8_DIGITS: keep the int8 base-256 digit planes at digits = 2 on every matrix (without it BitNet32-F16 matrices
+ *     take f16 activations on the f16 matrix cores, above)
+ *   BITNET_HIP_FUSE_FP6_DIGITS: digits = 2 on an unscaled matrix (QK256) whose code map lies in -2..2: the SAME 15-bit integer per
+ *     activation as three base-32 digits on the block-scaled fp6 x fp4 MFMA (k_gemm_fp6: same products, f32 accumulation of exact
+ *     integers -- bit-identical to the int8 form while every partial sum stays below 2^24); also the process default with
+ *     BITNET_HIP_GEMM_FP6=1.  Measured: 10-14 % faster per gate|up / down launch under sustained load, its quantiser 9-20 us slower
+ *     per launch: about even inside a prompt, hence opt-in */
 #define BITNET_HIP_FUSE_X_F16 2
 #define BITNET_HIP_FUSE_Y_F16 4
 #define BITNET_HIP_FUSE_INT8_DIGITS 8
+#define BITNET_HIP_FUSE_FP6_DIGITS 16
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
 int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
@@ -237,6 +241,10 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
  * scale folded into f16 weights and f16 activations: BitNet32-F16 at digits = 2).  The parity tests assert
  * that the instance bench.py times (2 digits, 64-token tile) is the one they compared with the oracle. */
 int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode);
+/* Output rows per wave of that launch: 64 (four 16-row tiles, 256-row workgroups) or 80 (five: the 320-row workgroups the forms with
+ * f32 accumulators take when they need fewer rounds of the chip -- 2560 output rows x 4096 tokens = 512 workgroups, one round);
+ * 0 before the thread's first tiled matmul.  scale_mode 5 = the f16 MFMA on an unscaled matrix, 6 = the fp6 x fp4 form (k_gemm_fp6). */
+int bitnet_hip_matmul_last_wave_rows(void);
 
 /* The prompt forward's f16 ACTIVATION CHAIN (north_star: "2-bit weight unpack x f16 activation dot product"; replaces the reference's
  * per-row loop T:683-691 / T:924 over many activation rows, K/cpu/quantized_matmul.rs:57-96 for the scaled format): every projection

@@ -174,6 +174,64 @@ def test_benchmarked_tile_matches_oracle(hip, oracle, torch_, layers, fmt, case)
     hip.weights_free(h)
 
 
+@pytest.mark.parametrize("fmt", ["qk256", "i2s"])
+@pytest.mark.parametrize("case", ["o", "down"])
+def test_benchmarked_f16_tile_of_the_2560_row_launches_matches_oracle(hip, oracle, torch_, layers, fmt, case):
+    """The o- / down-projection of the timed 4096-token prompt, BOTH formats (round 4): their inputs are f16 rows already (the attention
+    output, silu * up), so they go to the f16 matrix cores as they stand -- bitnet_hip_matmul_f16_dev, k_gemm_f16a in 320-row
+    workgroups (five row tiles per wave: 8 x 64 = 512 workgroups, one round of the chip), x = x + W h in place, plus the chain's
+    hand-over outputs (f16(gamma * x), LayerNorm partials).  Against the oracle's rows on the SAME f16 values: nothing is rounded
+    but the f32 accumulation, so the gate is 2e-6 of sum |w x| (the reference's own loops round about as much)."""
+    cfg, both = layers
+    lay = both[fmt]
+    name = case
+    rows, K = cfg.shapes()[name]
+    assert rows == 2560
+    rng = np.random.default_rng(zlib.crc32(f"f16/{fmt}/{case}".encode()))
+    sample = np.sort(rng.choice(M, SAMPLE, replace=False))
+    sample[0], sample[-1] = 0, M - 1
+    h = upload(hip, lay, fmt, name, rows, K)
+    assert hip.matmul_f16_supported(h)
+    x16 = (rng.normal(0.0, 1.0, (M, K)) * np.exp(rng.uniform(np.log(0.05), np.log(50.0), (M, 1)))).astype(np.float16)
+    res = rng.normal(0, 1, (M, rows)).astype(np.float32)
+    gout = rng.uniform(0.5, 1.5, rows).astype(np.float32)
+    xh = torch_.from_numpy(x16).cuda()
+    y = torch_.from_numpy(res).cuda()
+    yh = torch_.full((M, rows), float("nan"), dtype=torch_.float16, device="cuda")
+    st = torch_.full((rows // 64, M, 2), float("nan"), device="cuda")
+    hip.matmul_f16_dev(h, xh, M, y=y, residual=y, yh=yh, gamma_out=torch_.from_numpy(gout).cuda(), stats_out=st)
+    torch_.cuda.synchronize()
+    assert hip.matmul_last_tile() == dict(digits=2, wave_tokens=64, waves=4, scale_mode=5 if fmt == "qk256" else 4)
+    assert hip.matmul_last_wave_rows() == 80
+    got_all = y.cpu().numpy()
+    assert np.isfinite(got_all).all()
+    xs = x16[sample].astype(np.float32)
+    prod = oracle_rows(oracle, lay, fmt, name, rows, K, xs)
+    want = prod + res[sample]
+    if fmt == "qk256":
+        mag = np.abs(xs).astype(np.float64).sum(axis=1, keepdims=True) * 2.0  # |w| <= 2
+    else:
+        pk = lay[name].reshape(rows, K // 4)
+        codes = np.stack([(pk >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(rows, K)
+        wabs = ((codes == 1) | (codes == 3)) * np.repeat(np.abs(lay[name + "_scales"]).reshape(rows, K // 32), 32, axis=1)
+        mag = np.abs(xs).astype(np.float64) @ wabs.T.astype(np.float64)
+    err = np.abs(got_all[sample] - want)
+    assert np.all(err <= 2e-6 * mag + 1e-6 * np.abs(res[sample]) + 1e-6), float(np.max(err / (2e-6 * mag + 1e-6)))
+    for i in range(SAMPLE):
+        assert cosine(got_all[sample[i]] - res[sample[i]], prod[i]) >= 0.999999, int(sample[i])
+    # hand-over: f16(gamma_out * y) rounded once; the rows / 64 partial entries add up to the row's (sum, sum of squares) -- with
+    # 320-row workgroups the first rows / 80 entries are the waves' 80-row sums and the rest are zero
+    assert np.array_equal(yh.cpu().numpy(), (got_all * gout).astype(np.float16))
+    stn = st.cpu().numpy().astype(np.float64)
+    g64 = got_all.astype(np.float64)
+    assert np.all(np.abs(stn[:, :, 0].sum(axis=0) - g64.sum(axis=1)) <= 4e-6 * np.abs(g64).sum(axis=1) + 1e-6)
+    assert np.all(np.abs(stn[:, :, 1].sum(axis=0) - (g64 ** 2).sum(axis=1)) <= 4e-6 * (g64 ** 2).sum(axis=1) + 1e-6)
+    slabs = g64.reshape(M, rows // 80, 80)
+    assert np.all(np.abs(stn[: rows // 80, :, 0].T - slabs.sum(axis=2)) <= 4e-6 * np.abs(slabs).sum(axis=2) + 1e-6)
+    assert np.all(stn[rows // 80 :] == 0)
+    hip.weights_free(h)
+
+
 def _models(synth, fmt, cfg):
     glob = synth.make_globals(cfg)
     if fmt == "qk256":
@@ -260,8 +318,8 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
     dec.reset()
     dec.feed(prompt[:1024])
     dec.prefill(1024, with_logits=True, digits=2)
-    t = hip.matmul_last_tile()  # the last launch of the loop is a 2560-row down-projection: narrower tile at 1024 rows (QK256)
-    assert t["digits"] == 2 and t["scale_mode"] == (0 if fmt == "qk256" else 4)
+    t = hip.matmul_last_tile()  # the last launch of the loop is a 2560-row down-projection on the f16 matrix cores: narrower tile at 1024 rows
+    assert t["digits"] == 2 and t["scale_mode"] == (5 if fmt == "qk256" else 4)
     assert dec.position() == 1024
     c = cosine(dec.last_logits(), o_1k)
     assert c >= 0.9999, c
@@ -272,7 +330,8 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
         dec.feed(seq)  # every token forced to the oracle's
         dec.prefill(T, with_logits=True, digits=2)
         tile = hip.matmul_last_tile()
-        assert tile == expect_tile(fmt, "down_residual"), tile  # the prompt's last matmul is a down-projection
+        # the prompt's last matmul is a down-projection: k_gemm_f16a on f16 silu * up rows in 320-row workgroups, both formats
+        assert tile == dict(digits=2, wave_tokens=64, waves=4, scale_mode=5 if fmt == "qk256" else 4) and hip.matmul_last_wave_rows() == 80, tile
         assert dec.position() == T
         c = cosine(dec.last_logits(), o_logits[0])
         assert c >= 0.9999, (kv16, c)

@@ -256,3 +256,82 @@ def test_f16_handover_flags_of_the_digit_form(hip, torch_):
         hip.matmul_fused_dev(ha, ya, yb, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, digits=2, flags=2)  # X_F16 with a LayerNorm
     for h in (ha, hb, hg):
         hip.weights_free(h)
+
+
+INT8_DIGITS, FP6_DIGITS = 8, 16  # BITNET_HIP_FUSE_INT8_DIGITS, BITNET_HIP_FUSE_FP6_DIGITS
+
+
+@pytest.mark.parametrize("rows,cols,m", [(256, 256, 16), (3840, 2560, 200), (2560, 2560, 4096), (1000, 1100, 37), (2560, 6912, 512), (48, 512, 1)])
+def test_fp6_form_is_the_int8_two_digit_product_bit_for_bit(hip, oracle, torch_, rows, cols, m):
+    """k_gemm_fp6 (BITNET_HIP_FUSE_FP6_DIGITS): the 2-digit form's 15-bit integer per activation as three balanced base-32 digits in
+    fp6 (e2m3) x fp4 (e2m1) weights on v_mfma_scale_f32_16x16x128_f8f6f4, digit weights 1 / 32 / 1024 in the instruction's E8M0 block
+    scale, one f32 accumulator.  Every product and partial sum is an integer below 2^24 on these inputs, so the result must equal the
+    int8 digit planes' (BITNET_HIP_FUSE_INT8_DIGITS) bit for bit -- plain, behind the fused LayerNorm, with the residual, on odd shapes,
+    on the 64-token / narrow / 320-row tiles -- and with it inherits that form's oracle gates (checked once more on sampled rows)."""
+    rng = np.random.default_rng(rows * 7 + cols + m)
+    stride = -(-cols // 256) * 64
+    qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+    x = (rng.normal(0.1, 1.0, (m, cols)) * np.exp(rng.uniform(-3, 3, (m, 1)))).astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, cols) / 80).astype(np.float32)
+    res = rng.normal(0, 1, (m, rows)).astype(np.float32)
+    gd, rd = torch_.from_numpy(g).cuda(), torch_.from_numpy(res).cuda()
+    h = hip.weights_upload_qk256(qs, rows, cols, stride)
+    for kw in ({}, dict(ln_gamma=gd, ln_eps=1e-5), dict(residual=rd)):
+        y8 = run_gemm(hip, torch_, h, x, rows, 2, flags=INT8_DIGITS, **kw)
+        assert hip.matmul_last_tile()["scale_mode"] == 0
+        y6 = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS, **kw)
+        t = hip.matmul_last_tile()
+        assert t["scale_mode"] == 6 and t["digits"] == 2, t
+        if (rows, m) == (2560, 4096):
+            assert t["wave_tokens"] == 64 and hip.matmul_last_wave_rows() == 80  # 512 workgroups of 320 rows: one round of the chip
+        assert not np.isnan(y6).any()
+        assert np.array_equal(y8, y6), (sorted(kw), float(np.abs(y8 - y6).max()))
+    pick = np.unique(np.r_[0, m - 1, rng.integers(0, m, 6)])
+    want = np.stack([oracle.gemv_qk256(qs, x[i], rows, cols, stride) for i in pick])
+    got = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS)[pick]
+    for i in range(len(pick)):
+        assert cosine(got[i], want[i]) >= 0.99999, int(pick[i])
+    hip.weights_free(h)
+
+
+def test_fp6_form_silu_handover_and_refusals(hip, torch_):
+    """The fp6 form with the silu * mul epilogue and the f16 hand-over flags, against the int8 planes bit for bit; refused (never
+    silently replaced) where it does not apply: other digit counts, together with FUSE_INT8_DIGITS, matrices with block scales (the
+    instruction's block scale is a power of two; an unscaled matrix only comes from bitnet_hip_weights_upload_qk256)."""
+    rng = np.random.default_rng(21)
+    n, k, m = 512, 1024, 90
+    x = rng.normal(0, 2, (m, k)).astype(np.float32)
+    qa, qb = rng.integers(0, 256, n * k // 4, dtype=np.uint8), rng.integers(0, 256, n * k // 4, dtype=np.uint8)
+    ha, hb = hip.weights_upload_qk256(qa, n, k, k // 4), hip.weights_upload_qk256(qb, n, k, k // 4)
+    hg = hip.weights_concat([ha, hb], interleave16=True)
+    g = (rng.uniform(0.5, 1.5, k) / 80).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    wsb = hip.matmul_workspace_bytes(m, k, 2)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    xd = torch_.from_numpy(x).cuda()
+    outs = {}
+    for name, fl in (("int8", INT8_DIGITS), ("fp6", FP6_DIGITS)):
+        yf = torch_.empty(m, n, device="cuda")
+        yh = torch_.full((m, n), float("nan"), dtype=torch_.float16, device="cuda")
+        yx = torch_.empty(m, n, device="cuda")
+        hip.matmul_fused_dev(hg, xd, yf, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, flags=1 | fl, digits=2)
+        hip.matmul_fused_dev(hg, xd, yh, m, ws, wsb, ln_gamma=gd, ln_eps=1e-5, flags=1 | 4 | fl, digits=2)
+        hip.matmul_fused_dev(ha, xd.half(), yx, m, ws, wsb, flags=2 | fl, digits=2)
+        torch_.cuda.synchronize()
+        assert hip.matmul_last_tile()["scale_mode"] == (6 if name == "fp6" else 0)
+        outs[name] = (yf.cpu().numpy(), yh.cpu().numpy(), yx.cpu().numpy())
+    for a, b in zip(outs["int8"], outs["fp6"]):
+        assert np.isfinite(b.astype(np.float32)).all()
+        assert np.array_equal(a, b)
+    ya = torch_.empty(m, n, device="cuda")
+    with pytest.raises(Exception, match="FUSE_FP6_DIGITS"):
+        hip.matmul_fused_dev(ha, xd, ya, m, ws, wsb, digits=3, flags=FP6_DIGITS)
+    with pytest.raises(Exception, match="FUSE_FP6_DIGITS"):
+        hip.matmul_fused_dev(ha, xd, ya, m, ws, wsb, digits=2, flags=FP6_DIGITS | INT8_DIGITS)
+    codes = rng.integers(0, 4, (n, k), dtype=np.uint8)
+    packed = (codes[:, 0::4] | codes[:, 1::4] << 2 | codes[:, 2::4] << 4 | codes[:, 3::4] << 6).astype(np.uint8)
+    hs = hip.weights_upload_i2s(packed.reshape(-1), np.ones(n * (k // 32), np.float32), n, k, 32)
+    with pytest.raises(Exception, match="FUSE_FP6_DIGITS"):
+        hip.matmul_fused_dev(hs, xd, ya, m, ws, wsb, digits=2, flags=FP6_DIGITS)
+    for h in (ha, hb, hg, hs):
+        hip.weights_free(h)

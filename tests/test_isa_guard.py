@@ -27,7 +27,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ATTN = "_ZN10bitnet_hip14k_prefill_attnILi4ELi4ELi2EEEvNS_11PrefillArgsE"
 GEMM64 = "_ZN10bitnet_hip11k_gemm_mfmaILi2ELi4ELi0ELi2ELi1EEEvNS_8GemmArgsE"
 GEMM32 = "_ZN10bitnet_hip11k_gemm_mfmaILi2ELi2ELi0ELi2ELi1EEEvNS_8GemmArgsE"
-GEMMF16 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1EEEvNS_8GemmArgsEj"  # the f16 chain instance (BitNet32-F16, 64-token tile, chain epilogues)
+GEMMF16 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1ELi4EEEvNS_8GemmArgsEj"  # the f16 chain instance (BitNet32-F16, 64-token tile, chain epilogues)
+# the 320-row workgroups of the 2560-row launches (five row tiles per wave), BitNet32-F16 and QK256 (the hybrid prompt forward's o / down)
+GEMMF16_R5 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1ELi5EEEvNS_8GemmArgsEj"
+GEMMF16_R5_QK = "_ZN10bitnet_hip11k_gemm_f16aILi0ELi4ELi1ELi5EEEvNS_8GemmArgsEj"
+GEMMFP6 = "_ZN10bitnet_hip10k_gemm_fp6ILi4ELi4EEEvNS_8GemmArgsEj"  # the fp6 x fp4 form, 64-token tile (opt-in)
 
 
 def _compile(src, tmp):
@@ -96,11 +100,13 @@ VMEM = re.compile(r"^(global_|buffer_|flat_|scratch_)")
 def test_resources_of_the_benchmarked_instantiations(isa):
     _, ua = isa["kernels_prefill_attn.hip"]
     _, ug = isa["kernels_gemm.hip"]
-    for name, usage, ceiling in ((ATTN, ua, 230), (GEMM64, ug, 232), (GEMM32, ug, 168), (GEMMF16, ug, 200)):
+    for name, usage, ceiling in ((ATTN, ua, 230), (GEMM64, ug, 232), (GEMM32, ug, 168), (GEMMF16, ug, 200), (GEMMF16_R5, ug, 224), (GEMMF16_R5_QK, ug, 208),
+                                 (GEMMFP6, ug, 240)):
         u = usage[name]
         assert u["ScratchSize"] == 0, (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= ceiling, (name, u)
     assert ua[ATTN]["Occupancy"] >= 2 and ug[GEMM64]["Occupancy"] >= 2 and ug[GEMM32]["Occupancy"] >= 3 and ug[GEMMF16]["Occupancy"] >= 2
+    assert ug[GEMMF16_R5]["Occupancy"] >= 2 and ug[GEMMF16_R5_QK]["Occupancy"] >= 2 and ug[GEMMFP6]["Occupancy"] >= 2
 
 
 # the one instantiation hipcc 7.2 spills: 4 digits x 256-element block scales on the 8-wave tile (128 int32 + 64 f32 accumulators);
@@ -112,7 +118,7 @@ def test_no_scratch_anywhere_else_in_the_prefill_sources(isa):
     for src, (lines, usage) in isa.items():
         for name, u in usage.items():
             assert u["ScratchSize"] == 0 or name in KNOWN_SCRATCH, (src, name, u)
-    for name in (ATTN, GEMM64, GEMM32, GEMMF16):
+    for name in (ATTN, GEMM64, GEMM32, GEMMF16, GEMMF16_R5, GEMMF16_R5_QK, GEMMFP6):
         src = "kernels_prefill_attn.hip" if name == ATTN else "kernels_gemm.hip"
         assert not any(re.match(r"\s*scratch_", l) for l in body_of(isa[src][0], name)), name
 

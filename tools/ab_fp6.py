@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("bitnet-rs_amd")
-INT8 = 8  # BITNET_HIP_FUSE_INT8_DIGITS
+INT8, FP6 = 8, 16  # BITNET_HIP_FUSE_INT8_DIGITS, BITNET_HIP_FUSE_FP6_DIGITS
 
 
 def main():
@@ -38,7 +38,7 @@ def main():
             wsb = hip.matmul_workspace_bytes(m, k, 2)
             ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
             res = {}
-            for form, fl in (("int8", INT8), ("fp6", 0)):
+            for form, fl in (("int8", INT8), ("fp6", FP6)):
                 y = torch.full((m, n), float("nan"), device="cuda")
                 hip.matmul_fused_dev(h, x, y, m, ws, wsb, digits=2, flags=fl)
                 torch.cuda.synchronize()
