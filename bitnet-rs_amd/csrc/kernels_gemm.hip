@@ -891,11 +891,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
                     const uint32_t wd = m == 0 ? wc[rt].x : m == 1 ? wc[rt].y : m == 2 ? wc[rt].z : wc[rt].w;
                     // (s, s) of this lane's 32-block 2 g + (m >> 1): low / high half of its scale dword
                     const gh2 s2 = __builtin_bit_cast(gh2, __builtin_amdgcn_perm(0u, sc[rt], (m >> 1) ? 0x03020302u : 0x01000100u));
+#if defined(BH_ABLATE) && (BH_ABLATE & 2)  // developer build: no code expansion
+                    a[rt] = __builtin_bit_cast(gh8, (gv4u){wd, wd >> (h + 1), sc[rt], wd ^ lut_hi});
+#else
                     a[rt] = expand8_f16<FMT>(wd, h, lut_hi, s2);
+#endif
                 }
 #pragma unroll
                 for (int ct = 0; ct < TTW; ++ct) {
+#if defined(BH_ABLATE) && (BH_ABLATE & 1)  // developer build: no LDS operand reads
+                    const gh8 b = __builtin_bit_cast(gh8, (gv4u){(unsigned)(ct + blk), (unsigned)m, (unsigned)h, 1u});
+#else
                     const gh8 b = *reinterpret_cast<const gh8 *>(bcur + ct * 16 * ROWB + boff[2 * m + h]);
+#endif
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
                 }
