@@ -74,6 +74,9 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     obj_dir = OBJ_DIR + ("_diag" if diag else "")
     lib_path = LIB_PATH.replace(".so", "_diag.so") if diag else LIB_PATH
     extra_all = ["-DBH_STAMPS"] if diag else []
+    ig = os.environ.get("BH_IGLP")  # developer builds of kernels_gemm.hip with an IGroupLP strategy hint in the f16 matmul's K loop
+    if ig:
+        return _build(force, verbose, OBJ_DIR + "_iglp" + ig, LIB_PATH.replace(".so", f"_ablateiglp{ig}.so"), [f"-DBH_IGLP={ig}"])
     ab = os.environ.get("BH_ABLATE")  # developer builds of kernels_gemm.hip with parts of the loop removed (tools/ablate_gemm.py)
     if ab:
         obj_dir, lib_path, extra_all = OBJ_DIR + "_ablate" + ab, LIB_PATH.replace(".so", f"_ablate{ab}.so"), [f"-DBH_ABLATE={ab}", "-DBH_STAMPS"]

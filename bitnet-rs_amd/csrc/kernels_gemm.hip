@@ -881,6 +881,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 512);
         }
+#ifdef BH_IGLP
+        if (RT == 4) __builtin_amdgcn_iglp_opt(BH_IGLP);
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
