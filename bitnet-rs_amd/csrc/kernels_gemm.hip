@@ -794,6 +794,114 @@ __device__ __forceinline__ gh8 expand8_f16(uint32_t w, int h, uint32_t lut_hi, g
     return (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
 }
 
+// ---- the f16 chain's epilogues (k_gemm_f16a<.., EPI = 1>; NW = 8: the ring form of tools/probes/gemm_f16_ring.patch): NW waves of RT row tiles x TTW token tiles ------
+template <int RT, int TTW, int NW>
+__device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc)[RT][TTW], uint8_t *lds, int bx, int by, int rw, int c, int g, int tid) {
+    constexpr int WG_TOK = TTW * 16;
+    // LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma;
+    // mean / denom from the producer's per-slab partial sums of the exact f32 x, added up here in a fixed order (f64): deterministic
+    float2 *mu_rs = reinterpret_cast<float2 *>(lds);  // (the K loop's last barrier is behind every wave: the tile buffers are free)
+    if (p.stats_in) {
+        constexpr int NG = NW * 64 / WG_TOK;
+        double *red = reinterpret_cast<double *>(lds + 1024);
+        const int tk = tid % WG_TOK, pg = tid / WG_TOK;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = pg; i < p.n_stats; i += NG) {
+            const float2 v = *reinterpret_cast<const float2 *>(p.stats_in + 2 * ((size_t)i * p.stats_stride + by * WG_TOK + tk));
+            s1 += (double)v.x, s2 += (double)v.y;
+        }
+        red[2 * tid] = s1, red[2 * tid + 1] = s2;
+        __syncthreads();
+        if (tid < WG_TOK) {
+            s1 = s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) s1 += red[2 * (q * WG_TOK + tid)], s2 += red[2 * (q * WG_TOK + tid) + 1];
+            const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
+            const float denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+            mu_rs[tid] = float2{(float)mean_d, 1.0f / denom};
+        }
+        __syncthreads();
+    }
+    const int tile0 = bx * (NW * RT) + rw * RT;
+    float lng[RT][4], gout[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int row0 = 16 * (tile0 + rt) + 4 * g;
+        row0 = row0 + 3 < p.rows ? row0 : p.rows - 4;  // (rows % 256 == 0 on this path: never taken)
+        const float4 lg = p.stats_in ? *reinterpret_cast<const float4 *>(p.ln_g + row0) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 go = p.gamma_out ? *reinterpret_cast<const float4 *>(p.gamma_out + row0) : float4{1.f, 1.f, 1.f, 1.f};
+        lng[rt][0] = lg.x, lng[rt][1] = lg.y, lng[rt][2] = lg.z, lng[rt][3] = lg.w;
+        gout[rt][0] = go.x, gout[rt][1] = go.y, gout[rt][2] = go.z, gout[rt][3] = go.w;
+    }
+    typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        const int tok0 = (by * TTW + tt) * 16, token = tok0 + c;
+        const bool live = token < p.m;
+        float val[RT][4];
+        float2 mr = float2{0.f, 1.f};
+        if (p.stats_in) mr = mu_rs[tt * 16 + c];
+        const float is = p.inv_scale ? p.inv_scale[token] : 1.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[rt][j] = (acc[rt][tt][j] * is - mr.x * lng[rt][j]) * mr.y;
+        if (RT == 4 && p.silu_mul) {
+            // row tiles alternate (gate, up): FeedForward::forward T:756-781; the product goes out as f16 rows for the down-projection
+            const int half_rows = p.rows >> 1, ra = 16 * (tile0 >> 1) + 4 * g;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
+                    r[j] = gv / (1.0f + expf(-gv)) * uv;
+                }
+                if (live) {
+                    if (p.yh) {
+                        gh4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[j], -65504.0f, 65504.0f);
+                        *reinterpret_cast<gh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
+                    }
+                    if (p.y) store_out4(p.y + (size_t)token * half_rows + ra + 16 * pr, r[0], r[1], r[2], r[3]);
+                }
+            }
+            continue;
+        }
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row0 = 16 * (tile0 + rt) + 4 * g;
+            const size_t off = (size_t)(live ? token : 0) * p.rows + row0;
+            if (p.residual) {  // x = x + W h (in place: y aliases the residual), T:1073
+                const float4 rv = *reinterpret_cast<const float4 *>(p.residual + off);
+                val[rt][0] += rv.x, val[rt][1] += rv.y, val[rt][2] += rv.z, val[rt][3] += rv.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += val[rt][j], s2 += val[rt][j] * val[rt][j];
+            if (live) {
+                if (p.y) *reinterpret_cast<float4 *>(p.y + off) = float4{val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
+                if (p.yh) {
+                    gh4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(val[rt][j] * gout[rt][j], -65504.0f, 65504.0f);
+                    *reinterpret_cast<gh4 *>(p.yh + off) = o;
+                }
+            }
+        }
+        if (p.stats_out) {  // this wave's 16 RT rows of the token: the consumer's LayerNorm adds the slabs up
+            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+            if (g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(bx * NW + rw) * p.stats_stride + token)) = live ? float2{s1, s2} : float2{0.f, 0.f};
+            // RT == 5: rows / 80 partials fill the first slabs of the [rows / 64] array the interface names; the first NW / 4 waves of
+            // every workgroup clear the rows / 320 surplus ones (behind the NW gx real ones), so the consumer still adds rows / 64 entries up
+            if (RT == 5 && rw < NW / 4 && g == 0)
+                *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(NW * gridDim.x + bx * (NW / 4) + rw) * p.stats_stride + token)) = float2{0.f, 0.f};
+        }
+    }
+}
+
 // RT = row tiles per wave: 4 (256-row workgroups), or 5 (320-row workgroups, chain form only): a 2560-row matrix x 4096 tokens is then
 // 8 x 64 = 512 workgroups -- exactly one round of the 512 slots (two 4-wave workgroups per CU) instead of 640 in two rounds.
 template <int FMT, int TTW, int EPI = 0, int RT = 4>
@@ -928,108 +1036,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         return;
     }
-    // ---- the f16 chain's epilogues -------------------------------------------------------------------------------------------------
-    // LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma;
-    // mean / denom from the producer's per-slab partial sums of the exact f32 x, added up here in a fixed order (f64): deterministic
-    float2 *mu_rs = reinterpret_cast<float2 *>(lds);  // (the K loop's last barrier is behind every wave: the tile buffers are free)
-    if (p.stats_in) {
-        constexpr int NG = 256 / WG_TOK;
-        double *red = reinterpret_cast<double *>(lds + 1024);
-        const int tk = tid % WG_TOK, pg = tid / WG_TOK;
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = pg; i < p.n_stats; i += NG) {
-            const float2 v = *reinterpret_cast<const float2 *>(p.stats_in + 2 * ((size_t)i * p.stats_stride + by * WG_TOK + tk));
-            s1 += (double)v.x, s2 += (double)v.y;
-        }
-        red[2 * tid] = s1, red[2 * tid + 1] = s2;
-        __syncthreads();
-        if (tid < WG_TOK) {
-            s1 = s2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < NG; ++q) s1 += red[2 * (q * WG_TOK + tid)], s2 += red[2 * (q * WG_TOK + tid) + 1];
-            const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
-            const float denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
-            mu_rs[tid] = float2{(float)mean_d, 1.0f / denom};
-        }
-        __syncthreads();
-    }
-    const int tile0 = bx * (4 * RT) + rw * RT;
-    float lng[RT][4], gout[RT][4];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        int row0 = 16 * (tile0 + rt) + 4 * g;
-        row0 = row0 + 3 < p.rows ? row0 : p.rows - 4;  // (rows % 256 == 0 on this path: never taken)
-        const float4 lg = p.stats_in ? *reinterpret_cast<const float4 *>(p.ln_g + row0) : float4{0.f, 0.f, 0.f, 0.f};
-        const float4 go = p.gamma_out ? *reinterpret_cast<const float4 *>(p.gamma_out + row0) : float4{1.f, 1.f, 1.f, 1.f};
-        lng[rt][0] = lg.x, lng[rt][1] = lg.y, lng[rt][2] = lg.z, lng[rt][3] = lg.w;
-        gout[rt][0] = go.x, gout[rt][1] = go.y, gout[rt][2] = go.z, gout[rt][3] = go.w;
-    }
-    typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int tt = 0; tt < TTW; ++tt) {
-        const int tok0 = (by * TTW + tt) * 16, token = tok0 + c;
-        const bool live = token < p.m;
-        float val[RT][4];
-        float2 mr = float2{0.f, 1.f};
-        if (p.stats_in) mr = mu_rs[tt * 16 + c];
-        const float is = p.inv_scale ? p.inv_scale[token] : 1.0f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) val[rt][j] = (acc[rt][tt][j] * is - mr.x * lng[rt][j]) * mr.y;
-        if (RT == 4 && p.silu_mul) {
-            // row tiles alternate (gate, up): FeedForward::forward T:756-781; the product goes out as f16 rows for the down-projection
-            const int half_rows = p.rows >> 1, ra = 16 * (tile0 >> 1) + 4 * g;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    r[j] = gv / (1.0f + expf(-gv)) * uv;
-                }
-                if (live) {
-                    if (p.yh) {
-                        gh4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[j], -65504.0f, 65504.0f);
-                        *reinterpret_cast<gh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
-                    }
-                    if (p.y) store_out4(p.y + (size_t)token * half_rows + ra + 16 * pr, r[0], r[1], r[2], r[3]);
-                }
-            }
-            continue;
-        }
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int row0 = 16 * (tile0 + rt) + 4 * g;
-            const size_t off = (size_t)(live ? token : 0) * p.rows + row0;
-            if (p.residual) {  // x = x + W h (in place: y aliases the residual), T:1073
-                const float4 rv = *reinterpret_cast<const float4 *>(p.residual + off);
-                val[rt][0] += rv.x, val[rt][1] += rv.y, val[rt][2] += rv.z, val[rt][3] += rv.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s1 += val[rt][j], s2 += val[rt][j] * val[rt][j];
-            if (live) {
-                if (p.y) *reinterpret_cast<float4 *>(p.y + off) = float4{val[rt][0], val[rt][1], val[rt][2], val[rt][3]};
-                if (p.yh) {
-                    gh4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(val[rt][j] * gout[rt][j], -65504.0f, 65504.0f);
-                    *reinterpret_cast<gh4 *>(p.yh + off) = o;
-                }
-            }
-        }
-        if (p.stats_out) {  // this wave's 16 RT rows of the token: the consumer's LayerNorm adds the slabs up
-            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
-            if (g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(bx * 4 + rw) * p.stats_stride + token)) = live ? float2{s1, s2} : float2{0.f, 0.f};
-            // RT == 5: rows / 80 partials fill the first slabs of the [rows / 64] array the interface names; the workgroups' first waves
-            // clear the rows / 320 surplus ones (4 gx + bx), so the consumer still adds rows / 64 entries up
-            if (RT == 5 && rw == 0 && g == 0) *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(4 * gridDim.x + bx) * p.stats_stride + token)) = float2{0.f, 0.f};
-        }
-    }
+    f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, bx, by, rw, c, g, tid);
 }
 
 // ================================================================================================================================
