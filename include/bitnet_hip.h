@@ -256,7 +256,10 @@ int bitnet_hip_matmul_last_wave_rows(void);
  *   y (nullable): f32 rows [m][rows]; residual (nullable, may alias y): y = residual + W x (T:1073, T:1125).
  *   BITNET_HIP_FUSE_SILU_MUL: (gate, up) interleaved handle, outputs have rows / 2 columns (T:756-781).
  *   yh (nullable): the output as f16 rows [m_pad][rows or rows / 2], multiplied by gamma_out[row] first when given (the NEXT
- *                  LayerNorm's weight); stats_out (nullable): float2 [rows / 64][m_pad] partials of the f32 outputs for that LayerNorm.
+ *                  LayerNorm's weight); stats_out (nullable): float2 [rows / 64][m_pad] partials of the f32 outputs for that LayerNorm:
+ *                  (sum, sum of squares) over disjoint row ranges that together cover the row -- one per wave of the producing launch
+ *                  (64 rows, or 80 in 320-row workgroups: then the first rows / 80 entries are used and the others are written as zero);
+ *                  the consumer adds all rows / 64 entries up (n_stats = rows / 64).
  * bitnet_hip_matmul_f16_supported: rows % 256 == 0, cols % 256 == 0, code map values in -2..2, no scales or f16 32-block scales.
  * bitnet_hip_rows_to_f16_dev: the chain's entry (the embedding rows): xh = f16(gamma * x) (gamma nullable) + stats partial 0. */
 int bitnet_hip_matmul_f16_supported(bitnet_hip_weights_t w);

@@ -40,6 +40,9 @@ for case in range(n_cases):
     ln = fused and cols >= 32 and bool(rng.integers(0, 2))
     res = fused and bool(rng.integers(0, 2))
     digits = int(rng.choice([2, 3, 4]))
+    # 2 digits: the form is the launcher's choice (0), the int8 planes on request (8: BITNET_HIP_FUSE_INT8_DIGITS) or, on unscaled
+    # matrices, the fp6 x fp4 form (16: BITNET_HIP_FUSE_FP6_DIGITS)
+    form = int(rng.choice([0, 8, 16] if fmt == "qk256" else [0, 8])) if digits == 2 else 0
     if fused:
         gam = rng.uniform(0.5, 1.5, cols).astype(np.float32)
         resid = rng.normal(0, 1, (m, rows)).astype(np.float32)
@@ -65,11 +68,11 @@ for case in range(n_cases):
             else:
                 wsb = hip.matmul_workspace_bytes(m, cols, digits)
                 ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-                hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, ln_gamma=gd if ln else None, ln_eps=1e-5, residual=rd if res else None, digits=digits)
+                hip.matmul_fused_dev(h, xd, yd, m, ws, wsb, ln_gamma=gd if ln else None, ln_eps=1e-5, residual=rd if res else None, digits=digits, flags=form)
         torch.cuda.synchronize()
         got = yd.cpu().numpy()
         # 2 digits: 14-bit activations; on f16-scaled 32-blocks (cols % 256 == 0) the f16 matrix cores with f16 activations (2^-12 per element)
-        f16w = fused and m > 1 and digits == 2 and fmt == "i2s32h" and cols % 256 == 0
+        f16w = fused and m > 1 and digits == 2 and fmt == "i2s32h" and cols % 256 == 0 and form != 8
         tol = (3e-5 if not (fused and m > 1 and digits == 2) else 1.5e-3 if f16w else 3e-4) * max(1.0, float(np.max(np.abs(want)))) + 2e-4 * np.sqrt(cols / 256.0)
         err = float(np.max(np.abs(got - want)))
         ok = np.isfinite(got).all() and err <= tol
@@ -77,7 +80,7 @@ for case in range(n_cases):
         ok, err, tol = False, repr(e), 0
     if not ok:
         bad += 1
-        print("FAIL", fmt, rows, cols, m, "fused" if fused else "plain", "ln" if ln else "", "res" if res else "", digits, err, tol, flush=True)
+        print("FAIL", fmt, rows, cols, m, "fused" if fused else "plain", "ln" if ln else "", "res" if res else "", digits, form, err, tol, flush=True)
     hip.weights_free(h)
 print(f"{n_cases - bad}/{n_cases} cases agree with the oracle", flush=True)
 sys.exit(1 if bad else 0)
