@@ -752,10 +752,14 @@ bool Decoder::handover16_applies(int digits) const {
     return c_.ffn % 4 == 0;
 }
 
-// (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections)
-bool Decoder::hybrid_applies() const {
-    static const bool hybrid_env = !(getenv("BITNET_HOST_PREFILL_HYBRID") && atoi(getenv("BITNET_HOST_PREFILL_HYBRID")) == 0);
+// (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections, =2 takes the f16 form at
+// any length.)  Only where the f16 kernel runs on its 64-token tile, i.e. where hidden-row launches of 64-token tiles cover the chip's 512
+// workgroup slots: measured, QK256, same box -- 4096 tokens 20.7 -> 19.8 ms, 8192 tokens 45.3 -> 43.4, 2048 tokens 11.4 = 11.4, but 1024
+// tokens (the narrow f16 tiles; also one rank's share of the 8-GPU prompt) 7.2 -> 7.8 ms.
+bool Decoder::hybrid_applies(size_t n_rows) const {
+    static const int hybrid_env = getenv("BITNET_HOST_PREFILL_HYBRID") ? atoi(getenv("BITNET_HOST_PREFILL_HYBRID")) : 1;
     if (!hybrid_env || layers_.empty()) return false;
+    if (hybrid_env != 2 && ((size_t)c_.hidden / 256) * ((n_rows + 63) / 64) < 512) return false;
     for (const auto &L : layers_)
         if (bitnet_hip_matmul_f16_supported(L.o) != 1 || bitnet_hip_matmul_f16_supported(L.down) != 1) return false;
     return true;
@@ -870,7 +874,7 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     // Hybrid (unscaled matrices): the two projections whose inputs ARE f16 rows (the attention output, silu * up) multiply them on the f16
     // matrix cores as they stand (k_gemm_f16a, 320-row workgroups: one round of the chip at 4096 tokens) -- no quantiser launch, no second
     // rounding of values that were rounded to f16 already; q|k|v and gate|up keep the faster int8 digit planes behind their LayerNorm.
-    const bool hybrid = h16 && hybrid_applies();
+    const bool hybrid = h16 && hybrid_applies(N);
     for (auto &L : layers_) {
         if (chain) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
@@ -1037,7 +1041,7 @@ int Decoder::prefill_sharded(int n, int rank, int world, bitnet_host_allgather_f
         if (rc) return rc;
     }
     float *att_out = h16 ? static_cast<float *>(pf_atth_) : pf_att_;
-    const bool hybrid = h16 && hybrid_applies();  // o / down on the f16 matrix cores, as in the unsharded prefill
+    const bool hybrid = h16 && hybrid_applies(N);  // o / down on the f16 matrix cores, as in the unsharded prefill (long shares only)
     const int aflags = (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | (h16 ? BITNET_HIP_ATTN_OUT_F16 : 0);
     for (auto &L : layers_) {
         HCHK(mark(0, s));

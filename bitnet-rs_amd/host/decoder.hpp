@@ -116,7 +116,7 @@ class Decoder {
     int finish_prefill(int n, const float *last_row, bool with_logits);
     bool chain_applies(int digits) const;
     bool handover16_applies(int digits) const;
-    bool hybrid_applies() const;
+    bool hybrid_applies(size_t n_rows) const;
     int ensure_chain_buffers(size_t N);
     int prefill_chain_layers(size_t N);
     void set_phase_timing(bool on) { sp_timing_ = on; }

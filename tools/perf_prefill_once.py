@@ -1,6 +1,6 @@
 """4096-token prefills at the default digit count (for rocprofv3 --kernel-trace --stats and the --pmc passes).
 
-    python3 tools/perf_prefill_once.py [qk256|i2s] [repetitions = 3] [layers = 30]
+    python3 tools/perf_prefill_once.py [qk256|i2s] [repetitions = 3] [layers = 30] [tokens = 4096]
 
 The counter passes of tools/profile_round.sh run ONE repetition on 4 layers: the same launches per layer at the same
 shapes, few enough dispatches for rocprofv3's counter collection."""
@@ -17,10 +17,10 @@ for l in range(cfg.n_layers):
     w = synth.make_layer(cfg, l, fmt=fmt, block=32)
     dec.set_layer_qk256(l, w) if fmt == "qk256" else dec.set_layer_i2s(l, w, 32)
 dec.set_globals(synth.make_globals(cfg))
-T = 4096
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 prompt = synth.prompt(T, cfg.vocab)
 for rep in range(reps):
     dec.reset(); dec.feed(prompt)
     ms = dec.prefill(T, with_logits=True, digits=2)
-print(fmt, "layers", layers, "prefill ms", round(ms, 2), "tile", hip.matmul_last_tile(), flush=True)
+print(fmt, "layers", layers, "tokens", T, "prefill ms", round(ms, 2), "tile", hip.matmul_last_tile(), flush=True)
 dec.close()
