@@ -1255,9 +1255,12 @@ thread_local GemmTileChoice g_last_gemm_tile;  // what the last launch on this t
 //      1.25 rounds of work.  32-token tiles run THREE to a CU (132 registers, 32 KiB of LDS): 1280 tiles on 768 slots.  Measured,
 //      same box: o 74 -> 68 us, down 173 -> 160 us (quantiser included).  int8 form only: the f16 kernel's 32-token form (its staging
 //      and scale work per MFMA double) LOSES 2 % of the BitNet32-F16 prefill under the same rule.
-static int gemm_token_tiles(size_t gx0, size_t m_pad, bool tail_rule) {
+//  The f16 forms (cover = one workgroup per CU): their code expansion is a fixed cost per K step whatever the token tile, so a half-wide
+//  tile is barely shorter and only pays where it fills CUs that would idle -- measured, BitNet32-F16 chain, same box: 1024 tokens 9.52 ->
+//  8.42 ms, 2048 tokens 13.8 -> 13.3 ms with the 64- / 32-token tiles this rule takes (256 tokens: 4.9 ms either way).
+static int gemm_token_tiles(size_t gx0, size_t m_pad, bool tail_rule, size_t cover = 2 * kGemmCUs) {
     int ttw = 4;
-    while (ttw > 1 && gx0 * (m_pad / (16 * (size_t)ttw)) < 2 * kGemmCUs) ttw >>= 1;
+    while (ttw > 1 && gx0 * (m_pad / (16 * (size_t)ttw)) < cover) ttw >>= 1;
     if (ttw == 4 && tail_rule) {
         const size_t tiles = gx0 * (m_pad / 64), slots = 2 * kGemmCUs, rounds = div_ceil(tiles, slots);
         if (4 * tiles < 3 * rounds * slots) ttw = 2;  // the last round under a quarter full on average: < 75 % of the slots used
@@ -1368,7 +1371,7 @@ static hipError_t launch_gemm_f16(const Weights &w, const QuantArgs &q, const Ge
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     // token tile: 64 (TTW 4) while the grid still covers the chip twice over, else narrower (short prompts, one rank's share)
     const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
-    const int ttw = gemm_token_tiles(gx0, q.m_pad, false);
+    const int ttw = gemm_token_tiles(gx0, q.m_pad, false, kGemmCUs);
     const bool fmt1 = a.stiles_h != nullptr;
     void (*fk)(GemmArgs, uint32_t) = fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4> : ttw == 2 ? k_gemm_f16a<1, 2> : k_gemm_f16a<1, 1>)
                                           : (ttw == 4 ? k_gemm_f16a<0, 4> : ttw == 2 ? k_gemm_f16a<0, 2> : k_gemm_f16a<0, 1>);
@@ -1472,7 +1475,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     a.gamma_out = io.gamma_out;
     a.stats_out = io.stats_out;
     size_t gx0 = w.rows / 256;
-    const int ttw = gemm_token_tiles(gx0, m_pad, false);
+    const int ttw = gemm_token_tiles(gx0, m_pad, false, kGemmCUs);
     const bool fmt1 = w.scaled;
     const bool rt5 = ttw == 4 && !io.silu_mul && gemm_five_tiles(w.rows, m_pad);
     if (rt5) gx0 = w.rows / 320;

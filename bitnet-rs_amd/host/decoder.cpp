@@ -753,13 +753,13 @@ bool Decoder::handover16_applies(int digits) const {
 }
 
 // (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections, =2 takes the f16 form at
-// any length.)  Only where the f16 kernel runs on its 64-token tile, i.e. where hidden-row launches of 64-token tiles cover the chip's 512
-// workgroup slots: measured, QK256, same box -- 4096 tokens 20.7 -> 19.8 ms, 8192 tokens 45.3 -> 43.4, 2048 tokens 11.4 = 11.4, but 1024
-// tokens (the narrow f16 tiles; also one rank's share of the 8-GPU prompt) 7.2 -> 7.8 ms.
+// any length.)  Only for long shares -- where the hidden-row launches of 64-token tiles come to 400 workgroups or more (2560 tokens at
+// hidden 2560): measured, QK256, same box -- 4096 tokens 21.5 -> 20.3 ms, 3072 tokens 17.3 -> 16.4, 8192 tokens 45.3 -> 43.4, but 2048
+// tokens 11.8 -> 12.0 and 1024 tokens (also one rank's share of the 8-GPU prompt) 7.2 -> 7.8 ms.
 bool Decoder::hybrid_applies(size_t n_rows) const {
     static const int hybrid_env = getenv("BITNET_HOST_PREFILL_HYBRID") ? atoi(getenv("BITNET_HOST_PREFILL_HYBRID")) : 1;
     if (!hybrid_env || layers_.empty()) return false;
-    if (hybrid_env != 2 && ((size_t)c_.hidden / 256) * ((n_rows + 63) / 64) < 512) return false;
+    if (hybrid_env != 2 && ((size_t)c_.hidden / 256) * ((n_rows + 63) / 64) < 400) return false;
     for (const auto &L : layers_)
         if (bitnet_hip_matmul_f16_supported(L.o) != 1 || bitnet_hip_matmul_f16_supported(L.down) != 1) return false;
     return true;

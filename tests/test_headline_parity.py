@@ -266,8 +266,10 @@ def test_two_host_threads_share_the_library(hip, oracle, torch_):
             s = torch_.cuda.Stream()
             for it in range(40):
                 h = hip.weights_upload_qk256(qs[i], rows, cols, stride)
-                y = torch_.zeros(rows, device="cuda")
                 with torch_.cuda.stream(s):
+                    # (the output's zero fill rides on the SAME stream as the launch: torch's side streams do not synchronise with the
+                    # default stream, and a fill left there may land after the product -- seen once as a zero vector under two threads)
+                    y = torch_.zeros(rows, device="cuda")
                     hip.matmul_kernel_dev(h, xd, y, 1, 3 if it % 2 else 0, stream=s.cuda_stream)
                 s.synchronize()
                 if not np.all(approx_eq_with_len(y.cpu().numpy(), want[i], cols)):
