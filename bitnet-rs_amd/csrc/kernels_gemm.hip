@@ -1319,7 +1319,8 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
             // few activation rows (a short prompt, or one rank's share of a token-parallel prefill: 1024 rows x 2560 output rows
             // is 160 of these tiles for 512 slots): narrower token tiles until the grid covers the chip
             const size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
-            ttw = gemm_token_tiles(gx0, q.m_pad, true);
+            static const size_t cover = [] { const char *e = getenv("BITNET_HIP_I8_COVER"); return e ? (size_t)atoi(e) : 3 * kGemmCUs / 2; }();  // 384: swept 512 / 384 / 256 / 128 at 256 .. 2048 tokens, QK256 prompt -1 .. -3.5 % against 512
+            ttw = gemm_token_tiles(gx0, q.m_pad, true, cover);
             if (ttw == 2) gk = k_gemm_mfma<2, 2, 0, 2, 1>;
             if (ttw == 1) gk = k_gemm_mfma<2, 1, 0, 2, 1>;
         }
