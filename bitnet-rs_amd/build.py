@@ -77,6 +77,13 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     ig = os.environ.get("BH_IGLP")  # developer builds of kernels_gemm.hip with an IGroupLP strategy hint in the f16 matmul's K loop
     if ig:
         return _build(force, verbose, OBJ_DIR + "_iglp" + ig, LIB_PATH.replace(".so", f"_ablateiglp{ig}.so"), [f"-DBH_IGLP={ig}"])
+    sf = os.environ.get("BH_GEMM_SCHED")  # developer builds of kernels_gemm.hip under another LLVM scheduling strategy (max-ilp, ...)
+    if sf:
+        EXTRA["kernels_gemm.hip"] = ["-mllvm", f"-amdgpu-sched-strategy={sf}"]
+        try:
+            return _build(force, verbose, OBJ_DIR + "_sched_" + sf, LIB_PATH.replace(".so", f"_ablatesched{sf.replace('-', '')}.so"), ["-DBH_SCHED_VARIANT"])
+        finally:
+            EXTRA.pop("kernels_gemm.hip", None)
     ab = os.environ.get("BH_ABLATE")  # developer builds of kernels_gemm.hip with parts of the loop removed (tools/ablate_gemm.py)
     if ab:
         obj_dir, lib_path, extra_all = OBJ_DIR + "_ablate" + ab, LIB_PATH.replace(".so", f"_ablate{ab}.so"), [f"-DBH_ABLATE={ab}", "-DBH_STAMPS"]
