@@ -59,6 +59,7 @@ struct GemmArgs {
     _Float16 *yh = nullptr;            // f16 output rows [m_pad][rows] ([m_pad][rows / 2] with silu_mul), optionally x gamma_out[row]
     const float *gamma_out = nullptr;
     float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
+    unsigned long long *stamps = nullptr;  // diagnostic build (BH_STAMPS): per wave 8 x u64 of phase cycles, tools/stamp_f16a.py
 };
 
 struct QuantArgs {
@@ -967,6 +968,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
     }
     __syncthreads();
 
+#ifdef BH_STAMPS
+    // phase cycles of this wave (s_memtime), summed over the K steps: 0 staging stores (incl. their wait for the tile's loads), 1 issuing
+    // the next loads, 2 expansion + operand reads + MFMAs, 3 the barrier; 4 the prologue, 5 the epilogue (written by the caller side below)
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_prev = t_begin;
+#define F16A_PHASE(i)                                                    \
+    do {                                                                 \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();   \
+        ph[i] += t_now - t_prev;                                         \
+        t_prev = t_now;                                                  \
+    } while (0)
+#else
+#define F16A_PHASE(i) \
+    do {              \
+    } while (0)
+#endif
+#ifdef BH_STAMPS
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+    t_prev = t_loop;
+#endif
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = lds + (blk & 1) * kBuf;
         uint8_t *nxt = lds + ((blk + 1) & 1) * kBuf;
@@ -974,6 +996,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 #pragma unroll
             for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
         }
+        F16A_PHASE(0);
         gv4u wc[RT];
         uint32_t sc[RT];
 #pragma unroll
@@ -984,11 +1007,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
             for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
             if (FMT == 1) {
 #pragma unroll
+#if defined(BH_ABLATE) && (BH_ABLATE & 4)  // developer build: no scale loads in the loop
+                for (int rt = 0; rt < RT; ++rt) sn[rt] = 0x3C003C00u + (uint32_t)n1;
+#else
                 for (int rt = 0; rt < RT; ++rt) sn[rt] = sptr[rt][(size_t)n1 * 64];
+#endif
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 512);
         }
+        F16A_PHASE(1);
 #ifdef BH_IGLP
         if (RT == 4) __builtin_amdgcn_iglp_opt(BH_IGLP);
 #endif
@@ -1020,8 +1048,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
                 }
             }
         }
+        F16A_PHASE(2);
         __syncthreads();
+        F16A_PHASE(3);
     }
+#ifdef BH_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned long long *o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        o[0] = ph[0], o[1] = ph[1], o[2] = ph[2], o[3] = ph[3];
+        o[4] = t_loop - t_begin;
+        o[6] = t_begin;
+        o[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+#undef F16A_PHASE
     if (EPI == 0) {
 #pragma unroll
         for (int tt = 0; tt < TTW; ++tt) {
@@ -1475,6 +1515,9 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     a.yh = static_cast<_Float16 *>(io.yh);
     a.gamma_out = io.gamma_out;
     a.stats_out = io.stats_out;
+#ifdef BH_STAMPS
+    a.stamps = g_mfma_stamps;
+#endif
     size_t gx0 = w.rows / 256;
     const int ttw = gemm_token_tiles(gx0, m_pad, false, kGemmCUs);
     const bool fmt1 = w.scaled;
