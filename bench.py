@@ -416,7 +416,7 @@ def also_workloads(args, pkg, synth, hip, use_graph: bool):
     dec.reset()
     dec.feed(prompt)
     ms = dec.prefill(T, with_logits=True, digits=args.digits)
-    tile = hip.matmul_last_tile()
+    tile = dict(hip.matmul_last_tile(), wave_rows=hip.matmul_last_wave_rows())  # the prompt's last matmul: the down-projection (hybrid: f16 MFMA, 320-row workgroups)
     state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
     c4 = decode(dec, 128, 8)
     flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * T + 4.0 * T * T / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
@@ -652,7 +652,7 @@ def main():
         dec.reset()
         dec.feed(prompt)
         prefill_ms = dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
-        prefill_tile = hip.matmul_last_tile()
+        prefill_tile = dict(hip.matmul_last_tile(), wave_rows=hip.matmul_last_wave_rows())
         prefill_state = (dec.last_logits().astype(np.float64), int(dec.history(PROMPT_LEN + 1)[PROMPT_LEN]))
     else:
         dec.run(PROMPT_LEN - 1, with_logits=False, use_graph=use_graph)  # prompt positions (KV fill), untimed
@@ -756,7 +756,7 @@ def main():
             out["prefill"] = {"tokens": PROMPT_LEN, "ms": round(prefill_ms, 2), "tokens_per_s": round(PROMPT_LEN / prefill_ms * 1e3, 1),
                               "digits": args.digits, "eff_TFLOPs": round(flops / prefill_ms / 1e9, 1),
                               "note": "whole-prompt forward incl. first sampled token; QK256: q|k|v and gate|up on i8 MFMA digit planes behind their LayerNorm, o / down on f16 MFMA straight from the f16 rows their producers wrote (hybrid, DESIGN 4.6); BitNet32-F16: the f16 activation chain; attention on f16 MFMA",
-                              "last_matmul_tile": prefill_tile,  # the prompt's last matmul (a 2560-row down-projection: 32-token tiles at 4096 rows); roofline.tile = gate|up's
+                              "last_matmul_tile": prefill_tile,  # the prompt's last matmul (a 2560-row down-projection: f16 MFMA in 320-row workgroups at 4096 rows); roofline.tile = gate|up's
                               "prefill_check": prefill_chk, "roofline": prefill_roof}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
