@@ -60,6 +60,7 @@ struct GemmArgs {
     const float *gamma_out = nullptr;
     float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
     unsigned long long *stamps = nullptr;  // diagnostic build (BH_STAMPS): per wave 8 x u64 of phase cycles, tools/stamp_f16a.py
+    int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
 
 struct QuantArgs {
@@ -395,6 +396,11 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
             const int l = (id & 7) * (total >> 3) + (id >> 3);
             bx = l % gx;
             by = l / gx;
+            if (p.wgroup > 0) {  // weight-stationary walk: groups of `wgroup` row blocks, inside a group the token tiles, inside a tile the group's blocks
+                const int per = (int)gridDim.y * p.wgroup, grp = l / per, r = l - grp * per;
+                by = r / p.wgroup;
+                bx = grp * p.wgroup + (r - by * p.wgroup);
+            }
         }
     }
 
@@ -921,6 +927,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
             const int l = (id & 7) * (total >> 3) + (id >> 3);
             bx = l % gx;
             by = l / gx;
+            if (p.wgroup > 0) {  // weight-stationary walk: groups of `wgroup` row blocks, inside a group the token tiles, inside a tile the group's blocks
+                const int per = (int)gridDim.y * p.wgroup, grp = l / per, r = l - grp * per;
+                by = r / p.wgroup;
+                bx = grp * p.wgroup + (r - by * p.wgroup);
+            }
         }
     }
     const uint8_t *wptr[RT];
@@ -1119,6 +1130,11 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
             const int l = (id & 7) * (total >> 3) + (id >> 3);
             bx = l % gx;
             by = l / gx;
+            if (p.wgroup > 0) {  // weight-stationary walk: groups of `wgroup` row blocks, inside a group the token tiles, inside a tile the group's blocks
+                const int per = (int)gridDim.y * p.wgroup, grp = l / per, r = l - grp * per;
+                by = r / p.wgroup;
+                bx = grp * p.wgroup + (r - by * p.wgroup);
+            }
         }
     }
     const uint8_t *wptr[RT];
@@ -1315,6 +1331,25 @@ static bool gemm_five_tiles(size_t rows, size_t m_pad) {
     const size_t slots = 2 * kGemmCUs, tb = m_pad / 64;
     return div_ceil(rows / 320 * tb, slots) * 5 < div_ceil(div_ceil(rows, 256) * tb, slots) * 4;
 }
+// Weight-stationary walk of a launch.  In the plain order an XCD takes a band of token tiles and walks ALL row blocks for each: the
+// activation tile stays in its L2, the whole weight matrix streams through once per token tile (gate|up: 8.85 MB x 64 tiles = 566 MB of L2 misses
+// per launch, served by the Infinity Cache).  Grouped, an XCD takes `wgroup` row blocks -- the largest divisor of the row-block count whose codes
+// (+ scales) stay within 1.5 MiB of its 4 MiB L2 -- walks every token tile for them, then the next group: the weights are fetched about once, the
+// activation tiles once per group.  Measured (rocprofv3 --pmc FETCH_SIZE, tools/pmc_fetch_wgroup.sh): gate|up 589 -> 158 MB (QK256, groups of 9
+// row blocks), 752 -> 255 MB (BitNet32-F16); the 2560-row launches have few row blocks and wide activation bands and get WORSE (117 -> 188 MB),
+// so only launches of at least 24 row blocks take it.  Time: neutral (the re-reads were never what the K step waits for); results: identical.
+// BITNET_HIP_GEMM_WGROUP: -1 automatic (default), 0 off, n a fixed group.
+static int gemm_weight_group(size_t gx, size_t row_block_rows, size_t cols, bool f16_scales) {
+    static const int mode = [] { const char *e = getenv("BITNET_HIP_GEMM_WGROUP"); return e ? atoi(e) : -1; }();
+    if (mode == 0 || gx < 2) return 0;
+    if (mode > 0) return gx % (size_t)mode == 0 ? mode : 0;
+    if (gx < 24) return 0;
+    const size_t block_bytes = row_block_rows * cols / 4 + (f16_scales ? row_block_rows * cols / 16 : 0);
+    int best = 0;
+    for (size_t g = 2; g <= gx; ++g)
+        if (gx % g == 0 && g * block_bytes <= (size_t)3 << 19) best = (int)g;  // <= 1.5 MiB per group
+    return best;
+}
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -1379,7 +1414,9 @@ static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const Gemm
     }
     g_last_gemm_tile = GemmTileChoice{NDIG, 16 * ttw, 4 * cw, k32 ? 3 : !a.wscale ? 0 : bs32 ? 2 : 1};
     const unsigned gx = (unsigned)div_ceil(div_ceil(w.rows, 16), 16), gy = (unsigned)(q.m_pad / (16 * cw * ttw));
-    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, a);
+    GemmArgs aw = a;
+    if (!scaled_variant) aw.wgroup = gemm_weight_group(gx, 256, w.cols, false);
+    hipLaunchKernelGGL(gk, dim3(gx, gy), dim3(256 * cw), lds, stream, aw);
     return hipGetLastError();
 }
 
@@ -1538,6 +1575,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5, rt5 ? 80 : 64};
     const size_t lds = (size_t)2 * ttw * 16 * 512;  // (the epilogue's 5 KiB of statistics scratch fit the smallest tile pair: 16 KiB)
+    a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, w.cols, fmt1);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
 }
