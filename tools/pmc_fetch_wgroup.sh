@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 F=${1:-qk256}
-for g in 0 -1; do
+for g in ${GROUPS_LIST:-0 -1}; do
   O=gpurun_out/pmc_wgroup_${F}_$g
   rm -rf $O; mkdir -p $O
   export BITNET_HIP_GEMM_WGROUP=$g
