@@ -69,6 +69,7 @@ struct PrefillArgs {
     int phase;               // 0: prepare q, k, v and attend; 1: the query slabs only (needs no k|v: runs beside the all-gather);
                              // 2: the k / v slabs and the attention (the query slabs were prepared by a phase-1 call on the same workspace)
     int ksplit;
+    int split_tiles;         // key tiles one workgroup walks at least before a query block is cut (attn_split_tiles)
     float *part_o;           // [ksplit][nq_pad][heads][128]
     float *part_ml;          // [ksplit][nq_pad][heads][2]  (running maximum in base-2 units, sum)
 };
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
         // ksplit), so early blocks (few tiles) stay whole and late ones spread over the chip; surplus workgroups only mark their
         // partial empty (m = -inf), which the merge skips
         const int n_t = kt_last + 1;
-        int parts = (n_t + kTilesPerSplit - 1) / kTilesPerSplit;
+        int parts = (n_t + p.split_tiles - 1) / p.split_tiles;
         parts = parts < p.ksplit ? parts : p.ksplit;
         if ((int)blockIdx.z >= parts) {
             if (g == 0) {
@@ -566,12 +567,16 @@ __global__ __launch_bounds__(256) void k_prefill_merge(PrefillArgs p) {
 
 // key splits of a launch (grid.z): only when the query blocks alone leave CUs idle (fewer than two workgroups per CU), as many
 // as the longest block has 16-tile parts, at most 8
+static int attn_split_tiles() {
+    static const int v = [] { const char *e = getenv("BITNET_HIP_ATTN_SPLIT_TILES"); const int x = e ? atoi(e) : kTilesPerSplit; return x < 1 ? 1 : x; }();
+    return v;
+}
 static int attn_ksplit(int n_heads, int n_kv, int nq_pad, int T) {
     const int group = n_heads / n_kv, hw = group % 4 == 0 ? 4 : group % 2 == 0 ? 2 : 1, qg = 16 * (4 / hw) * 2;
     const long n_wg = (long)(nq_pad / qg) * (n_heads / hw);
     const int tiles = (T + kQB - 1) / kQB;
     if (n_wg >= 512) return 1;
-    const int s = (tiles + kTilesPerSplit - 1) / kTilesPerSplit;
+    const int s = (tiles + attn_split_tiles() - 1) / attn_split_tiles();
     return s < 1 ? 1 : s > 8 ? 8 : s;
 }
 
@@ -670,6 +675,7 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.vt = p.kh + (size_t)n_kv * p.Tpad * kPD;
     p.out = out;
     p.ksplit = attn_ksplit(n_heads, n_kv, p.nq_pad, T);
+    p.split_tiles = attn_split_tiles();
     p.part_o = reinterpret_cast<float *>(ws + attn_f16_bytes(n_heads, n_kv, (size_t)p.nq_pad, (size_t)p.Tpad));
     p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     p.phase = phase;
@@ -734,6 +740,7 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.vt = p.kh + (size_t)n_heads * p.Tpad * kPD;
     p.out = out;
     p.ksplit = attn_ksplit(n_heads, n_heads, p.nq_pad, seq);
+    p.split_tiles = attn_split_tiles();
     p.part_o = reinterpret_cast<float *>(ws + attn_f16_bytes(n_heads, n_heads, (size_t)p.nq_pad, (size_t)p.Tpad));
     p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     const unsigned nb = (unsigned)(p.nq_pad / kQB);
