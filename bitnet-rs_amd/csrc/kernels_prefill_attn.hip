@@ -70,6 +70,8 @@ struct PrefillArgs {
                              // 2: the k / v slabs and the attention (the query slabs were prepared by a phase-1 call on the same workspace)
     int ksplit;
     int split_tiles;         // key tiles one workgroup walks at least before a query block is cut (attn_split_tiles)
+    int slot0;               // k_prefill_prep: first slot of its grid (n_heads: the query slabs are prepared by k_prefill_attn itself)
+    int q_in_kernel;         // k_prefill_attn reads the f32 query rows itself (RoPE, scale, f16) instead of the f16 image k_prefill_prep left
     float *part_o;           // [ksplit][nq_pad][heads][128]
     float *part_ml;          // [ksplit][nq_pad][heads][2]  (running maximum in base-2 units, sum)
 };
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void k_prefill_prep(PrefillArgs p) {
     // one 64-token x 128-dim slab through LDS; every global access is 16 bytes wide (8 for f16 rows) and contiguous along the
     // fastest index of its tensor (the scalar version of this kernel took 48 us per layer for 115 MB of traffic)
     __shared__ __attribute__((aligned(16))) float tile[kQB][kPD + 4];  // + 4: float4 rows stay 16-byte aligned, columns spread over the banks
-    const int slot = blockIdx.y, t0 = blockIdx.x * kQB, tid = threadIdx.x;
+    const int slot = blockIdx.y + p.slot0, t0 = blockIdx.x * kQB, tid = threadIdx.x;
     const bool is_q = slot < p.n_heads, is_k = !is_q && slot < p.n_heads + p.n_kv;
     if ((p.phase == 1 && !is_q) || (p.phase == 2 && is_q)) return;
     const int n_rows = is_q ? p.nq : p.T;
@@ -289,14 +291,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     int qlim[NQ];  // highest visible key position of this lane's query in group q
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qlim[q] = p.causal ? bpos + 16 * q + c : p.T - 1;
-    // Q^T operands: 8 consecutive dims per k-slot group, kept in registers for the whole block
+    // Q^T operands: 8 consecutive dims per k-slot group, kept in registers for the whole block (filled below, behind the first tile requests)
     v8h qreg[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const _Float16 *qp = p.qh + ((size_t)h * p.nq_pad + qbase + 16 * q + c) * kPD + 8 * g;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) qreg[q][ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
-    }
     v4f o[NQ][8];
     float m_run[NQ], l_run[NQ];
 #pragma unroll
@@ -360,6 +356,53 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_prefill_attn(Prefi
     stage_k(kt_first, 0);
     stage_v(kt_first, 0);
     if (kt_first < kt_last) stage_k(kt_first + 1, 1);
+    // the query operands, requested BEHIND the first K / V^T tiles so that their round trip (strided f32 rows + the RoPE tables) overlaps the tiles'
+    if (p.q_in_kernel) {
+        // straight from the f32 rows of the q|k|v projection (round 4: two thirds of k_prefill_prep's traffic were the query slabs): a lane's
+        // dims 32 ch + 8 g + i (ch < 4) hold both members of every rotation pair (d, d + 64) = (ch, ch + 2), so the split-half RoPE
+        // (crates/bitnet-rope/src/lib.rs:59-93, T:134-163) needs no exchange; the same arithmetic as k_prefill_prep, the softmax scale and the
+        // change to base 2 folded into the f16 image.  Rows past the last query are zeros.  Every load is unconditional (clamped row).
+        const float qmul = 1.4426950408889634f * p.scale;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = qbase + 16 * q + c;
+            const bool live = row < p.nq;
+            const float *qp = p.q + (size_t)h * p.hs_q + (size_t)(live ? row : 0) * p.ld_q + 8 * g;
+            float x[4][8];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float4 a = *reinterpret_cast<const float4 *>(qp + 32 * ch), b = *reinterpret_cast<const float4 *>(qp + 32 * ch + 4);
+                x[ch][0] = a.x, x[ch][1] = a.y, x[ch][2] = a.z, x[ch][3] = a.w, x[ch][4] = b.x, x[ch][5] = b.y, x[ch][6] = b.z, x[ch][7] = b.w;
+            }
+            if (p.rope) {
+                const int pos = live ? bpos + 16 * q + c : 0;
+                const float *sp = p.rope_sin + (size_t)pos * 64 + 8 * g, *cp = p.rope_cos + (size_t)pos * 64 + 8 * g;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float4 s0 = *reinterpret_cast<const float4 *>(sp + 32 * ch), s1 = *reinterpret_cast<const float4 *>(sp + 32 * ch + 4);
+                    const float4 c0 = *reinterpret_cast<const float4 *>(cp + 32 * ch), c1 = *reinterpret_cast<const float4 *>(cp + 32 * ch + 4);
+                    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float x0 = x[ch][i], x1 = x[ch + 2][i];
+                        x[ch][i] = x0 * cs[i] - x1 * sn[i];
+                        x[ch + 2][i] = x0 * sn[i] + x1 * cs[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qreg[q][ch][i] = live ? (_Float16)(x[ch][i] * qmul) : (_Float16)0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const _Float16 *qp = p.qh + ((size_t)h * p.nq_pad + qbase + 16 * q + c) * kPD + 8 * g;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) qreg[q][ch] = *reinterpret_cast<const v8h *>(qp + 32 * ch);
+        }
+    }
     // the builtin form, so that hipcc's own bookkeeping sees its q loads retired here: left to itself it re-waits for them with
     // s_waitcnt vmcnt(0..7) in front of the MFMAs of EVERY iteration -- which, in hardware, waits for the tile requests it cannot see
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -680,11 +723,20 @@ hipError_t launch_attn_prefill(const float *q, int ld_q, const int *q_block_pos,
     p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     p.phase = phase;
     const unsigned nbq = (unsigned)(p.nq_pad / kQB), nbk = (unsigned)(p.Tpad / kQB);
-    if (phase == 1) {  // the query slabs alone
-        hipLaunchKernelGGL(k_prefill_prep, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
+    static const bool q_in_kernel = !(getenv("BITNET_HIP_ATTN_Q_IN_KERNEL") && atoi(getenv("BITNET_HIP_ATTN_Q_IN_KERNEL")) == 0);
+    // the attention kernel needs 16-byte aligned f32 query rows for its own q path; anything else keeps the f16 image of the prep kernel
+    p.q_in_kernel = q_in_kernel && (ld_q & 3) == 0 && ((uintptr_t)q & 15) == 0 ? 1 : 0;
+    p.slot0 = 0;
+    if (phase == 1) {  // the query slabs alone (nothing to do when the attention kernel prepares them itself)
+        if (!p.q_in_kernel) hipLaunchKernelGGL(k_prefill_prep, dim3(nbq, (unsigned)n_heads), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
+    if (p.q_in_kernel) {
+        p.slot0 = n_heads;
+        hipLaunchKernelGGL(k_prefill_prep, dim3(nbk, (unsigned)(2 * n_kv)), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(k_prefill_prep, dim3(nbq > nbk ? nbq : nbk, (unsigned)(n_heads + 2 * n_kv)), dim3(256), 0, stream, p);
+    }
     return launch_attn_kernel(p, stream);
 }
 
@@ -741,6 +793,8 @@ hipError_t launch_attn_generic(const float *q, const float *k, const float *v, f
     p.out = out;
     p.ksplit = attn_ksplit(n_heads, n_heads, p.nq_pad, seq);
     p.split_tiles = attn_split_tiles();
+    p.slot0 = 0;
+    p.q_in_kernel = 0;
     p.part_o = reinterpret_cast<float *>(ws + attn_f16_bytes(n_heads, n_heads, (size_t)p.nq_pad, (size_t)p.Tpad));
     p.part_ml = p.part_o + (size_t)p.ksplit * p.nq_pad * n_heads * kPD;
     const unsigned nb = (unsigned)(p.nq_pad / kQB);
