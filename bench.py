@@ -211,6 +211,44 @@ def exact_step_check(dec, synth, cfg, n_tokens: int = 6):
             "same_greedy_token": bool(ta == tb), "tokens_forced": n_tokens, "gate": ">= 0.99 (north_star), tests hold >= 0.9999"}
 
 
+def oracle_step_check(dec, synth, cfg, fmt: str, n_tokens: int = 4):
+    """The fast (fused, hipGraph) step against the CPU ORACLE at the benchmarked model's full depth and vocabulary: n_tokens forced
+    tokens through both, logits of the last one compared (cosine, max |diff|, greedy token).  Part of the cpu_baseline leg (rank 0,
+    N = 1), outside every timed region; the oracle is the checker here, never the thing measured.  QK256: the reference's live
+    path (gemv_qk256 per projection, T:589-702); BitNet32-F16: the dense f32 matrices the reference's loader makes of 32-element
+    flavours (M/gguf_simple.rs:1260-1285), held as codes + scales and multiplied in the dense loop's order (oracle "ternary" kind).
+    tests/test_full_depth_parity.py is the long form (16 + 8 greedy tokens, a run across key 257)."""
+    from oracle import oracle as orc
+
+    orc.build()
+    try:
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), 16))
+    except AttributeError:
+        n_thr = max(1, min(os.cpu_count() or 1, 16))
+    t0 = time.perf_counter()
+    layers = []
+    for l in range(cfg.n_layers):
+        w = synth.make_layer(cfg, l, fmt=fmt, block=32)
+        layers.append(dict(w, ternary=32) if fmt == "i2s" else w)
+    om = orc.OracleModel(cfg, layers, _GLOBALS[(cfg.vocab, cfg.hidden)], n_threads=n_thr)
+    toks = synth.prompt(n_tokens, cfg.vocab)
+    want = None
+    for i, t in enumerate(toks):
+        _, want, _ = om.step(int(t), want_logits=i == n_tokens - 1)
+    om.close()
+    dec.reset()
+    dec.feed(toks)
+    if n_tokens > 1:
+        dec.run(n_tokens - 1, with_logits=False, use_graph=True)
+    dec.run(1, with_logits=True, use_graph=True)
+    a, b = dec.last_logits().astype(np.float64), want.astype(np.float64)
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+    return {"logits_cosine_fast_step_vs_cpu_oracle": round(cos, 8), "max_abs_diff_over_max_abs": float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300)),
+            "same_greedy_token": bool(int(dec.history(n_tokens + 1)[n_tokens]) == orc.argmax(want)), "tokens_forced": n_tokens, "layers": cfg.n_layers,
+            "vocab": cfg.vocab, "format": "BitNet32-F16 (oracle: dense t(code) x scale, dense-loop order)" if fmt == "i2s" else "QK256 (oracle: gemv_qk256 per projection)",
+            "oracle_host_threads": n_thr, "wall_s": round(time.perf_counter() - t0, 1), "gate": ">= 0.99 (north_star); tests/test_full_depth_parity.py holds >= 0.999"}
+
+
 def i2s_stream(hip, synth, fmt: str = "i2s", layers_worth: int = 64, reps: int = 12, launches: int | None = None, isolated_only: bool = False):
     """The decode GEMV's STREAMING rate: the very kernel instance of the fused gate|up launch (k_gemv_q<8, 5, SC, LN, 1>: LayerNorm
     after the product, silu*mul, QAct in and out) over ONE matrix of `layers_worth` gate|up matrices laid end to end -- 64 x
@@ -380,10 +418,12 @@ def also_workloads(args, pkg, synth, hip, use_graph: bool):
     t_begin = time.perf_counter()
     out = {}
 
-    def decode(dec, steps, warmup):
+    def decode(dec, steps, warmup, rewind=None):
         if use_graph:
             dec.prepare_graphs(True)
         dec.run(warmup, with_logits=True, use_graph=use_graph)
+        if rewind is not None:  # back to the state right behind the prompt: the timed steps then start at the FIRST decode position
+            rewind()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev_ms = dec.run(steps, with_logits=True, use_graph=use_graph)
@@ -396,51 +436,64 @@ def also_workloads(args, pkg, synth, hip, use_graph: bool):
                 "roofline": {"bound": "hbm", "kernel": "k_gemv_q (fused LayerNorm -> gate|up GEMV -> silu*mul)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": int(ab), "us_per_launch": round(us, 3)}}
 
+    T = 4096
+    flops = None
     # ---- configs[2]: QK256, batch-1 decode after a 128-token prompt (f32 KV cache, as `--workload c3`); the decoder's cache is sized for c4
     cfg, dec, _ = build_model(pkg, synth, "c4", None)
-    prompt = synth.prompt(128, cfg.vocab)
-    dec.reset()
-    dec.feed(prompt)
-    dec.run(127, with_logits=False, use_graph=use_graph)
-    dec.run(1, with_logits=True, use_graph=use_graph)
-    c3 = decode(dec, 128, 16)
-    c3["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt", "kv_len_during_timing": [145, 273], "kv_cache": "f32"}
-    out["c3"] = c3
-    # ---- configs[3]: 4096-token prefill + decode at 4.1 - 4.2 k keys, f16 KV cache (the c4 default)
-    T = 4096
-    prompt = synth.prompt(T, cfg.vocab)
-    dec.reset()
-    dec.set_kv_f16(True)
-    dec.feed(prompt)
-    dec.prefill(T, with_logits=True, digits=args.digits)  # untimed warm-up pass
-    dec.reset()
-    dec.feed(prompt)
-    ms = dec.prefill(T, with_logits=True, digits=args.digits)
-    tile = dict(hip.matmul_last_tile(), wave_rows=hip.matmul_last_wave_rows())  # the prompt's last matmul: the down-projection (hybrid: f16 MFMA, 320-row workgroups)
-    state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
-    c4 = decode(dec, 128, 8)
-    flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * T + 4.0 * T * T / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
-    c4["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, 4096-token prefill + decode", "kv_len_during_timing": [T + 1 + 8, T + 1 + 8 + 128],
-                    "kv_cache": "f16 (values rounded once, when appended)"}
-    c4["prefill"] = {"tokens": T, "ms": round(ms, 2), "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
-                     "last_matmul_tile": tile, "prefill_check": prefill_check(dec, prompt, T, args.digits, state),
-                     "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, True)}
-    out["c4"] = c4
-    dec.close()
-    # ---- the same prompt through the headline storage format (BitNet32-F16: k_gemm_f16w on the f16 matrix cores at 2 digits)
+    try:
+        prompt = synth.prompt(128, cfg.vocab)
+        dec.reset()
+        dec.feed(prompt)
+        dec.run(127, with_logits=False, use_graph=use_graph)
+        dec.run(1, with_logits=True, use_graph=use_graph)
+        c3 = decode(dec, 128, 16)
+        c3["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, batch=1 decode, 128-token prompt", "kv_len_during_timing": [145, 273], "kv_cache": "f32"}
+        c3["i2s_stream"] = i2s_stream(hip, synth, "qk256", args.stream_layers) if not args.no_stream else None  # the QK256 twin of the headline's i2s_stream
+        out["c3"] = c3
+        # ---- configs[3] AS WRITTEN: 4096-token prefill + 512 decode steps at 4097 .. 4609 keys, f16 KV cache (the c4 default)
+        prompt = synth.prompt(T, cfg.vocab)
+        dec.reset()
+        dec.set_kv_f16(True)
+        dec.feed(prompt)
+        dec.prefill(T, with_logits=True, digits=args.digits)  # untimed warm-up pass
+        dec.reset()
+        dec.feed(prompt)
+        ms = dec.prefill(T, with_logits=True, digits=args.digits)
+        tile = dict(hip.matmul_last_tile(), wave_rows=hip.matmul_last_wave_rows())  # the prompt's last matmul: the down-projection (hybrid: f16 MFMA, 320-row workgroups)
+        state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
+
+        def rewind():
+            dec.reset()
+            dec.feed(prompt)
+            dec.prefill(T, with_logits=True, digits=args.digits)
+
+        c4 = decode(dec, 512, 8, rewind)
+        flops = 2.0 * 2_084_044_800 * (cfg.n_layers / 30) * T + 4.0 * T * T / 2 * cfg.n_heads * cfg.head_dim * cfg.n_layers
+        c4["config"] = {"workload": "bitnet-b1.58-2B-4T I2_S QK256 blocks, 1xMI355X, 4096-token prefill + 512 decode", "kv_len_during_timing": [T + 1, T + 1 + 512],
+                        "kv_cache": "f16 (values rounded once, when appended)",
+                        "note": "8 warm-up steps, then the prompt is prefilled again and the 512 timed steps start at the first decode position"}
+        c4["prefill"] = {"tokens": T, "ms": round(ms, 2), "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
+                         "last_matmul_tile": tile, "prefill_check": prefill_check(dec, prompt, T, args.digits, state),
+                         "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, True)}
+        out["c4"] = c4
+    finally:
+        dec.close()
+    # ---- the same prompt through the headline storage format (BitNet32-F16: k_gemm_f16a on the f16 matrix cores at 2 digits)
     cfg, dec, _ = build_model(pkg, synth, "c2", None, max_pos=T + 128)
-    dec.reset()
-    dec.set_kv_f16(True)
-    dec.feed(prompt)
-    dec.prefill(T, with_logits=True, digits=args.digits)
-    dec.reset()
-    dec.feed(prompt)
-    ms = dec.prefill(T, with_logits=True, digits=args.digits)
-    state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
-    out["prefill_i2s"] = {"workload": "bitnet-b1.58-2B-4T I2_S BitNet32-F16, 1xMI355X, 4096-token prefill", "tokens": T, "ms": round(ms, 2),
-                          "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
-                          "prefill_check": prefill_check(dec, prompt, T, args.digits, state), "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, False)}
-    dec.close()
+    try:
+        dec.reset()
+        dec.set_kv_f16(True)
+        dec.feed(prompt)
+        dec.prefill(T, with_logits=True, digits=args.digits)
+        dec.reset()
+        dec.feed(prompt)
+        ms = dec.prefill(T, with_logits=True, digits=args.digits)
+        state = (dec.last_logits().astype(np.float64), int(dec.history(T + 1)[T]))
+        out["prefill_i2s"] = {"workload": "bitnet-b1.58-2B-4T I2_S BitNet32-F16, 1xMI355X, 4096-token prefill", "tokens": T, "ms": round(ms, 2),
+                              "tokens_per_s": round(T / ms * 1e3, 1), "digits": args.digits, "eff_TFLOPs": round(flops / ms / 1e9, 1),
+                              "prefill_check": prefill_check(dec, prompt, T, args.digits, state), "roofline": prefill_roofline(hip, dec, cfg, T, args.digits, False)}
+    finally:
+        dec.close()
     out["wall_s"] = round(time.perf_counter() - t_begin, 1)
     return out
 
@@ -562,7 +615,7 @@ def bench_sharded_prefill(args, pkg, synth, dist_, r, hip, cfg, dec):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 256; 512 for --workload c4: BASELINE configs[3] = 4k-token prefill + 512 decode)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "stream"])
     ap.add_argument("--stream-layers", type=int, default=64, help="i2s_stream: gate|up matrices laid end to end (64 = 708 MB BitNet32-F16 / 566 MB QK256)")
@@ -589,6 +642,8 @@ def main():
     ap.add_argument("--kv32", action="store_true", help="c4: keep the f32 KV cache (the reference's type, T:1171-1202)")
     ap.add_argument("--exact-act", action="store_true", help="exact f32 activations between the kernels (round 1's path) instead of QAct")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 512 if args.workload == "c4" else 256
 
     # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU) BEFORE anything here
     # touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Under torchrun WORLD_SIZE must agree.
@@ -661,6 +716,14 @@ def main():
         dec.prepare_graphs(True)  # every attention form's step graph is built up front (a form first met inside the timed steps
                                   # would otherwise be captured there: ~2 ms of host work, not part of a decode step)
     dec.run(args.warmup, with_logits=True, use_graph=use_graph)      # W untimed warm-up steps
+    kv0 = PROMPT_LEN + 1 + args.warmup
+    if args.workload == "c4":
+        # configs[3] as written: the timed decode steps start right behind the prompt (4097 keys at the first one), so the warm-up's
+        # positions are given back: the prompt is prefilled again (untimed) before the timed region
+        dec.reset()
+        dec.feed(prompt)
+        dec.prefill(PROMPT_LEN, with_logits=True, digits=args.digits)
+        kv0 = PROMPT_LEN + 1
 
     ev = {}
 
@@ -671,7 +734,7 @@ def main():
     elapsed = dist_.timed_region(r, timed)
     ev_ms = ev["ms"]
     value = dist_.aggregate_throughput(r, args.steps, elapsed)
-    tokens = dec.history(PROMPT_LEN + 1 + args.warmup + args.steps)
+    tokens = dec.history(kv0 + args.steps)
 
     # dominant kernel: the fused gate|up GEMV (largest byte stream of a layer).  Every
     # layer's instance back to back (distinct weights: 30 x 13-17 MB > L2, cycling the
@@ -702,6 +765,9 @@ def main():
     # outside the timed region: the fast step against the UNFUSED step on the reference-order (bit-exact) kernels, same
     # weights, same short prompt, at the full model size -- a wrong fast kernel cannot hide behind a plausible rate
     check = exact_step_check(dec, synth, cfg) if not args.no_exact_check else None
+    oracle_check = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not gguf:
+        oracle_check = oracle_step_check(dec, synth, cfg, "qk256" if args.workload in ("c3", "c4", "c5") else "i2s")
     stream_res = None
     if not args.no_stream and args.workload in ("c2", "c3") and n_gpus == 1 and not gguf and not args.layers:
         stream_res = i2s_stream(hip, synth, "i2s" if args.workload == "c2" else "qk256", args.stream_layers)
@@ -734,7 +800,7 @@ def main():
                 else f"bitnet-b1.58-2B-4T I2_S QK256 blocks, {n_gpus}xMI355X, {PROMPT_LEN}-token prefill + decode",
                 "layers": cfg.n_layers,
                 "prompt_len": PROMPT_LEN,
-                "kv_len_during_timing": [PROMPT_LEN + 1 + args.warmup, PROMPT_LEN + 1 + args.warmup + args.steps],
+                "kv_len_during_timing": [kv0, kv0 + args.steps],
                 "parallelism": f"replicas x{n_gpus}" if n_gpus > 1 else "single GPU",
                 "launch": "hipGraph replay per token" if use_graph else "eager",
                 "kv_cache": "f16 (values rounded once, when appended; --kv32 keeps the reference's f32)" if kv16 else "f32 (as the reference, T:1171-1202)",
@@ -748,6 +814,7 @@ def main():
             "last_tokens": [int(t) for t in tokens[-4:]],
             "distinct_tokens_in_timed_steps": int(len(set(int(t) for t in tokens[-args.steps:]))),
             "exact_step_check": check,
+            "oracle_step_check": oracle_check,
         }
         if stream_res is not None:
             out["i2s_stream"] = stream_res
@@ -760,12 +827,15 @@ def main():
                               "prefill_check": prefill_chk, "roofline": prefill_roof}
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, synth)
+    also_failed = False
     if n_gpus == 1 and args.workload == "c2" and not args.no_also and not gguf and not args.layers and not args.exact_act:
         dec.close()  # the headline model's memory goes back first
         try:
             out["also"] = also_workloads(args, pkg, synth, hip, use_graph)
-        except Exception as e:  # noqa: BLE001 -- reported in the line, never in the way of the headline numbers
+        except Exception as e:  # noqa: BLE001 -- reported in the line (the headline numbers above still reach the driver) AND as a failed run
             out["also"] = {"error": f"{type(e).__name__}: {e}"}
+            out["failed"] = "also: c3 / c4 / BitNet32-F16 prefill did not complete (exit code 1)"
+            also_failed = True
     # N > 1: the decode line above is N independent replicas (batch-1 decode does not shard); the path's ONE real collective
     # -- the token-parallel prefill of BASELINE configs[4] -- runs here too, over the same ranks, and rides in the same line
     c5 = None
@@ -810,6 +880,8 @@ def main():
         print(json.dumps(out), flush=True)
     dec.close()
     dist_.finalize(r)
+    if also_failed:
+        sys.exit(1)  # a broken prefill / QK256 decode path must not look like a clean run
 
 
 if __name__ == "__main__":

@@ -1118,8 +1118,9 @@ int bitnet_hip_attention_prefill_gathered_dev(const float *q, size_t ld_q, const
                                               size_t n_ctx, size_t world, int kv_is_f16, const float *rope_sin, const float *rope_cos,
                                               void *kcache, void *vcache, int cache_f16, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_pos,
                                               void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    // cache_f16 is a BOOLEAN on this entry (any non-zero value = f16 caches, as before the phase entry gave the word its flag bits)
     return bitnet_hip_attention_prefill_gathered_phase_dev(q, ld_q, q_block_pos, n_q, kv_gathered, n_ctx, world, kv_is_f16, rope_sin, rope_cos, kcache, vcache,
-                                                           cache_f16, n_heads, n_kv_heads, head_dim, max_pos, workspace, workspace_bytes, out, 0, stream);
+                                                           cache_f16 ? BITNET_HIP_ATTN_CACHE_F16 : 0, n_heads, n_kv_heads, head_dim, max_pos, workspace, workspace_bytes, out, 0, stream);
 }
 
 int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q, size_t ld_q, const int32_t *q_block_pos, size_t n_q, const void *kv_gathered,
@@ -1128,6 +1129,8 @@ int bitnet_hip_attention_prefill_gathered_phase_dev(const float *q, size_t ld_q,
                                                     size_t max_pos, void *workspace, size_t workspace_bytes, float *out, int phase, void *stream) {
     BH_GUARD_BEGIN
     if (phase < 0 || phase > 2) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: phase must be 0, 1 or 2, got %d", phase);
+    if (cache_f16 & ~(BITNET_HIP_ATTN_CACHE_F16 | BITNET_HIP_ATTN_OUT_F16))  // a flag word here: unknown bits are refused, as attention_prefill_flags_dev does
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered_phase: unknown flag bits 0x%x (BITNET_HIP_ATTN_CACHE_F16 | BITNET_HIP_ATTN_OUT_F16)", cache_f16);
     int rc = check_prefill_args(q, kv_gathered, rope_sin, rope_cos, kcache, vcache, workspace, out, n_heads, n_kv_heads, head_dim, max_pos, n_ctx);
     if (rc) return rc;
     if (n_q == 0 || !q_block_pos) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "attention_prefill_gathered: n_q and q_block_pos must be given");

@@ -710,7 +710,14 @@ __global__ __launch_bounds__(256) void k_quant_rows_f16(QuantArgs p) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + 256 * i, ci = idx < nvec ? idx : nvec - 1;
-        v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        if (p.x_f16) {  // (wave-uniform) f16 rows from the producing kernel (BITNET_HIP_FUSE_X_F16), as k_quant_rows reads them:
+                        // without this branch the QK256 route of BITNET_HIP_GEMM_F16A=1 read the f16 buffer as f32 rows
+            typedef _Float16 qh4 __attribute__((ext_vector_type(4)));
+            const qh4 hv = *reinterpret_cast<const qh4 *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)rr * p.cols + 4 * ci);
+            v[i] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {
+            v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        }
         if (idx >= nvec || !live) v[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
     if (p.ln_gamma) {  // LayerNorm without bias, with mean subtraction (T:67-100): the same arithmetic as k_quant_rows

@@ -753,8 +753,8 @@ bool Decoder::handover16_applies(int digits) const {
 }
 
 // (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections, =2 takes the f16 form at
-// any length.)  Only for long shares -- where the hidden-row launches of 64-token tiles come to 400 workgroups or more (2560 tokens at
-// hidden 2560): measured, QK256, same box -- 4096 tokens 21.5 -> 20.3 ms, 3072 tokens 17.3 -> 16.4, 8192 tokens 45.3 -> 43.4, but 2048
+// any length.)  Only for long shares -- where the hidden-row launches of 64-token tiles come to 400 workgroups or more (from 2497 tokens at
+// hidden 2560: 40 token tiles x 10 row blocks): measured, QK256, same box -- 4096 tokens 21.5 -> 20.3 ms, 3072 tokens 17.3 -> 16.4, 8192 tokens 45.3 -> 43.4, but 2048
 // tokens 11.8 -> 12.0 and 1024 tokens (also one rank's share of the 8-GPU prompt) 7.2 -> 7.8 ms.
 bool Decoder::hybrid_applies(size_t n_rows) const {
     static const int hybrid_env = getenv("BITNET_HOST_PREFILL_HYBRID") ? atoi(getenv("BITNET_HOST_PREFILL_HYBRID")) : 1;

@@ -227,18 +227,96 @@ int bo_gemv_qk256_avx2(const uint8_t *qs, size_t qs_len, const float *x, size_t 
     return 0;
 }
 
+/* ---- persistent host thread pool (test infrastructure) ------------------------------------
+ * The threaded entry points used to create and join their threads per call (210 GEMVs per
+ * token x n threads).  bo_parallel_for keeps up to 63 workers alive for the life of the process;
+ * a call deals tasks 0 .. n_tasks-1 to at most n_threads participants (the caller included).
+ * A task is a fixed partition of independent outputs (row range / head range), so results do
+ * not depend on which thread runs it.  One parallel region at a time (callers are serialised). */
+#define BO_POOL_MAX 63
+static struct {
+    pthread_mutex_t mu, call_mu;
+    pthread_cond_t go, done;
+    pthread_t th[BO_POOL_MAX];
+    int n_workers;
+    unsigned long gen;
+    bo_task_fn fn;
+    void *arg;
+    int n_tasks, next, finished, max_extra, joined;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, NULL, NULL, 0, 0, 0, 0, 0};
+
+static void pool_drain(void) { /* g_pool.mu held on entry and on exit */
+    while (g_pool.next < g_pool.n_tasks) {
+        int t = g_pool.next++;
+        bo_task_fn fn = g_pool.fn;
+        void *arg = g_pool.arg;
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(arg, t);
+        pthread_mutex_lock(&g_pool.mu);
+        if (++g_pool.finished == g_pool.n_tasks) pthread_cond_broadcast(&g_pool.done);
+    }
+}
+static void *pool_worker(void *p) {
+    (void)p;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+        seen = g_pool.gen;
+        if (g_pool.joined < g_pool.max_extra) { /* at most n_threads - 1 workers beside the caller */
+            ++g_pool.joined;
+            pool_drain();
+        }
+    }
+    return NULL;
+}
+int bo_pool_workers(void) { return g_pool.n_workers; }
+void bo_parallel_for(int n_tasks, int n_threads, bo_task_fn fn, void *arg) {
+    if (n_tasks <= 0) return;
+    if (n_threads > n_tasks) n_threads = n_tasks;
+    if (n_threads > BO_POOL_MAX + 1) n_threads = BO_POOL_MAX + 1;
+    if (n_threads < 2) {
+        for (int t = 0; t < n_tasks; ++t) fn(arg, t);
+        return;
+    }
+    pthread_mutex_lock(&g_pool.call_mu);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.n_workers < n_threads - 1) {
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&g_pool.th[g_pool.n_workers], &at, pool_worker, NULL) != 0) {
+            pthread_attr_destroy(&at);
+            break; /* fewer helpers than asked for: the caller drains what is left */
+        }
+        pthread_attr_destroy(&at);
+        ++g_pool.n_workers;
+    }
+    g_pool.fn = fn, g_pool.arg = arg, g_pool.n_tasks = n_tasks, g_pool.next = 0, g_pool.finished = 0;
+    g_pool.max_extra = n_threads - 1, g_pool.joined = 0;
+    ++g_pool.gen;
+    pthread_cond_broadcast(&g_pool.go);
+    pool_drain();
+    while (g_pool.finished < g_pool.n_tasks) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    g_pool.n_tasks = 0; /* a late waker finds nothing to take */
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool.call_mu);
+}
+
 struct mt_arg {
     const uint8_t *qs;
     const float *x;
     float *y;
-    size_t r0, r1, rows, cols, stride;
+    size_t per, rows, cols, stride;
 };
-static void *mt_worker(void *p) {
+static void mt_task(void *p, int t) {
     struct mt_arg *a = (struct mt_arg *)p;
-    gemv_rows_avx2(a->qs, a->x, a->y, a->r0, a->r1, a->rows, a->cols, a->stride);
-    return NULL;
+    size_t r0 = min_sz(a->rows, a->per * (size_t)t), r1 = min_sz(a->rows, r0 + a->per);
+    if (r0 < r1) gemv_rows_avx2(a->qs, a->x, a->y, r0, r1, a->rows, a->cols, a->stride);
 }
 
+/* gemv_qk256_avx2 (Q/i2s_qk256_avx2.rs:254-295) with the rows partitioned over n_threads host threads (the reference's row loop
+ * is single-threaded: this is the "all cores" baseline of SURVEY 8d).  Rows are independent dot products: bit-identical to one thread. */
 int bo_gemv_qk256_avx2_mt(const uint8_t *qs, size_t qs_len, const float *x, size_t x_len,
                           float *y, size_t y_len, size_t rows, size_t cols,
                           size_t row_stride_bytes, int n_threads, char *err) {
@@ -250,17 +328,8 @@ int bo_gemv_qk256_avx2_mt(const uint8_t *qs, size_t qs_len, const float *x, size
     if (rc) return rc;
     if (n_threads < 1) n_threads = 1;
     if ((size_t)n_threads > rows) n_threads = (int)(rows ? rows : 1);
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
-    struct mt_arg *args = (struct mt_arg *)malloc(sizeof(struct mt_arg) * (size_t)n_threads);
-    size_t per = div_ceil(rows, (size_t)n_threads);
-    for (int t = 0; t < n_threads; ++t) {
-        size_t r0 = min_sz(rows, per * (size_t)t), r1 = min_sz(rows, r0 + per);
-        args[t] = (struct mt_arg){qs, x, y, r0, r1, rows, cols, row_stride_bytes};
-        pthread_create(&th[t], NULL, mt_worker, &args[t]);
-    }
-    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
-    free(th);
-    free(args);
+    struct mt_arg a = {qs, x, y, div_ceil(rows, (size_t)n_threads), rows, cols, row_stride_bytes};
+    bo_parallel_for(n_threads, n_threads, mt_task, &a);
     return 0;
 }
 

@@ -56,7 +56,12 @@ int bo_gemv_qk256(const uint8_t *qs, size_t qs_len, const float *x, size_t x_len
                   float *y, size_t y_len, size_t rows, size_t cols,
                   size_t row_stride_bytes, char *err);
 int bo_have_avx2(void);
-/* Row-partitioned, n_threads pthreads, each running the AVX2 row kernel
+/* Test-infrastructure thread pool: tasks 0 .. n_tasks-1 run on at most n_threads threads (the
+ * caller included); workers persist for the life of the process (created on first use). */
+typedef void (*bo_task_fn)(void *arg, int task);
+void bo_parallel_for(int n_tasks, int n_threads, bo_task_fn fn, void *arg);
+int bo_pool_workers(void);
+/* Row-partitioned over n_threads pool threads, each running the AVX2 row kernel
  * ("reference kernel, parallelised" -- BASELINE.md section 3 mode (b)). */
 int bo_gemv_qk256_avx2_mt(const uint8_t *qs, size_t qs_len, const float *x, size_t x_len,
                           float *y, size_t y_len, size_t rows, size_t cols,
@@ -161,6 +166,12 @@ void bo_model_destroy(void *m);
 int bo_model_set_layer(void *m, int layer, const float *attn_norm, const float *ffn_norm,
                        const uint8_t *q, const uint8_t *k, const uint8_t *v, const uint8_t *o,
                        const uint8_t *gate, const uint8_t *up, const uint8_t *down);
+/* projections as dense f32 [out, in] (32-element I2_S flavours are dequantised at load: M/gguf_simple.rs:1260-1285) */
+int bo_model_set_layer_dense(void *m, int layer, const float *attn_norm, const float *ffn_norm, const float *const *w7);
+/* the same dense matrices held as ternary codes + one f32 scale per (row, block): W = t(code) * scale, multiplied on the fly in
+ * the dense loop's order (= i2s_matmul_f32, K/cpu/quantized_matmul.rs:57-96) */
+int bo_model_set_layer_ternary(void *m, int layer, const float *attn_norm, const float *ffn_norm,
+                               const uint8_t *const *codes7, const float *const *scales7, int block);
 void bo_model_set_globals(void *m, const uint16_t *embed_f16, const float *final_norm);
 void *bo_kv_create(void *m);
 void bo_kv_destroy(void *kv);

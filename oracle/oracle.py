@@ -362,7 +362,15 @@ class OracleModel:
         L.bo_model_set_layer_dense.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.POINTER(_f32p)]
         for i, w in enumerate(layers):
             a = [np.ascontiguousarray(w["attn_norm"], np.float32), np.ascontiguousarray(w["ffn_norm"], np.float32)]
-            if w.get("dense"):  # projections as dense f32 [out, in] (loader-dequantised flavours)
+            if w.get("ternary"):  # BitNet32 storage as synth.make_layer(fmt="i2s") returns it: packed codes + "<name>_scales", W = t(code) * scale
+                names = ("q", "k", "v", "o", "gate", "up", "down")
+                a += [np.ascontiguousarray(w[k], np.uint8) for k in names] + [np.ascontiguousarray(w[k + "_scales"], np.float32) for k in names]
+                self._keep.append(a)
+                cp = (_u8p * 7)(*[x.ctypes.data_as(_u8p) for x in a[2:9]])
+                sp = (_f32p * 7)(*[x.ctypes.data_as(_f32p) for x in a[9:16]])
+                L.bo_model_set_layer_ternary.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.POINTER(_u8p), C.POINTER(_f32p), C.c_int]
+                rc = L.bo_model_set_layer_ternary(self.m, i, a[0].ctypes.data_as(_f32p), a[1].ctypes.data_as(_f32p), cp, sp, int(w["ternary"]))
+            elif w.get("dense"):  # projections as dense f32 [out, in] (loader-dequantised flavours)
                 a += [np.ascontiguousarray(w[k], np.float32) for k in ("q", "k", "v", "o", "gate", "up", "down")]
                 self._keep.append(a)
                 wp = (_f32p * 7)(*[x.ctypes.data_as(_f32p) for x in a[2:]])

@@ -35,6 +35,13 @@ typedef struct {
      * the tensor at load time (32-element I2_S flavours, M/gguf_simple.rs:1260-1285; then the
      * plain candle Linear path T:546-588) */
     const float *dense[7];
+    /* the same dense matrix held as the file holds it: ternary codes (K/cuda/quantized_matmul.rs:19-27: 0 -> 0, 1 -> +1,
+     * 2 -> 0, 3 -> -1), four per byte LSB-first, each output row's codes contiguous, and one f32 scale per (row, block):
+     * W[r, c] = t(code) * scale[r, c / block].  proj() multiplies W[r, c] on the fly in the dense loop's order -- the loop of
+     * i2s_matmul_f32, K/cpu/quantized_matmul.rs:57-96 -- so a full-size model needs 26 MB per layer instead of 278 MB of f32. */
+    const uint8_t *tern[7];
+    const float *tern_scales[7];
+    int tern_block;
 } bo_layer;
 
 typedef struct {
@@ -155,8 +162,7 @@ struct attn_arg {
     int n_heads, n_kv_heads, dim, max_pos, t_k, h0, h1;
     float *out;
 };
-static void *attn_worker(void *p) {
-    struct attn_arg *a = (struct attn_arg *)p;
+static void attn_heads(const struct attn_arg *a) {
     int group = a->n_heads / a->n_kv_heads, dim = a->dim, t_k = a->t_k;
     float scale = 1.0f / sqrtf((float)dim);
     float *scores = (float *)malloc(sizeof(float) * (size_t)t_k);
@@ -185,7 +191,17 @@ static void *attn_worker(void *p) {
         }
     }
     free(scores);
-    return NULL;
+}
+struct attn_job {
+    struct attn_arg base;
+    int per;
+};
+static void attn_task(void *p, int t) {
+    struct attn_job *j = (struct attn_job *)p;
+    struct attn_arg a = j->base;
+    a.h0 = t * j->per;
+    a.h1 = a.h0 + j->per > a.n_heads ? a.n_heads : a.h0 + j->per;
+    if (a.h0 < a.h1) attn_heads(&a);
 }
 void bo_attention_decode_mt(const float *q, const float *kc, const float *vc, int n_heads, int n_kv_heads, int dim,
                             int max_pos, int t_k, float *out, int n_threads) {
@@ -193,50 +209,85 @@ void bo_attention_decode_mt(const float *q, const float *kc, const float *vc, in
         bo_attention_decode(q, kc, vc, n_heads, n_kv_heads, dim, max_pos, t_k, out);
         return;
     }
-    pthread_t th[64];
-    struct attn_arg args[64];
     int nt = n_threads > 64 ? 64 : n_threads;
     if (nt > n_heads) nt = n_heads;
-    int per = (n_heads + nt - 1) / nt;
-    int used = 0;
-    for (int t = 0; t < nt; ++t) {
-        int h0 = t * per, h1 = h0 + per > n_heads ? n_heads : h0 + per;
-        if (h0 >= h1) break;
-        args[t] = (struct attn_arg){q, kc, vc, n_heads, n_kv_heads, dim, max_pos, t_k, h0, h1, out};
-        pthread_create(&th[t], NULL, attn_worker, &args[t]);
-        ++used;
-    }
-    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+    struct attn_job job = {{q, kc, vc, n_heads, n_kv_heads, dim, max_pos, t_k, 0, 0, out}, (n_heads + nt - 1) / nt};
+    bo_parallel_for(nt, nt, attn_task, &job);
 }
 
 /* dense f32 projection, rows dealt to threads: each row's dot product is the loop of proj() below, bit for bit */
 struct dense_arg {
     const float *W, *x;
+    const uint8_t *codes; /* ternary kind: codes + scales instead of W */
+    const float *scales;
+    int block;
     float *y;
-    int r0, r1, cols;
+    int per, rows, cols;
 };
-static void *dense_worker(void *p) {
-    struct dense_arg *a = (struct dense_arg *)p;
-    for (int r = a->r0; r < a->r1; ++r) {
+/* K/cuda/quantized_matmul.rs:19-27 */
+static inline float tern_value(unsigned bits) { return bits == 1 ? 1.0f : bits == 3 ? -1.0f : 0.0f; }
+static void dense_rows(const struct dense_arg *a, int r0, int r1) {
+    if (a->W) {
+        for (int r = r0; r < r1; ++r) {
+            float acc = 0.0f;
+            for (int c = 0; c < a->cols; ++c) acc += a->x[c] * a->W[(size_t)r * a->cols + c];
+            a->y[r] = acc;
+        }
+        return;
+    }
+    /* the loop of i2s_matmul_f32 (K/cpu/quantized_matmul.rs:57-96; bo_i2s_matmul_f32): wv = t(code) * scale, acc += a * wv,
+     * columns left to right -- the dense loop above on W[r, c] = t * scale, value for value */
+    const size_t packed_k = ((size_t)a->cols + 3) / 4, nbk = ((size_t)a->cols + (size_t)a->block - 1) / (size_t)a->block;
+    static const float TV[4] = {0.0f, 1.0f, 0.0f, -1.0f};
+    int r = r0;
+    /* four rows at a time: four independent accumulator chains (each row's own sum is still strictly left to right; rows are
+     * independent outputs), which is what lets a host core run the 2 G weights of a full-size token in a fraction of a second */
+    for (; r + 4 <= r1; r += 4) {
+        const uint8_t *w0 = a->codes + (size_t)r * packed_k, *w1 = w0 + packed_k, *w2 = w1 + packed_k, *w3 = w2 + packed_k;
+        const float *s0 = a->scales + (size_t)r * nbk, *s1 = s0 + nbk, *s2 = s1 + nbk, *s3 = s2 + nbk;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (size_t blk = 0; blk < nbk; ++blk) {
+            size_t c0 = blk * (size_t)a->block, c1 = c0 + (size_t)a->block > (size_t)a->cols ? (size_t)a->cols : c0 + (size_t)a->block;
+            const float k0 = s0[blk], k1 = s1[blk], k2 = s2[blk], k3 = s3[blk];
+            for (size_t c = c0; c < c1; ++c) {
+                const unsigned sh = (unsigned)(c & 3) * 2;
+                const float xv = a->x[c];
+                a0 += xv * (TV[(w0[c >> 2] >> sh) & 3u] * k0);
+                a1 += xv * (TV[(w1[c >> 2] >> sh) & 3u] * k1);
+                a2 += xv * (TV[(w2[c >> 2] >> sh) & 3u] * k2);
+                a3 += xv * (TV[(w3[c >> 2] >> sh) & 3u] * k3);
+            }
+        }
+        a->y[r] = a0, a->y[r + 1] = a1, a->y[r + 2] = a2, a->y[r + 3] = a3;
+    }
+    for (; r < r1; ++r) {
+        const uint8_t *wr = a->codes + (size_t)r * packed_k;
+        const float *sr = a->scales + (size_t)r * nbk;
         float acc = 0.0f;
-        for (int c = 0; c < a->cols; ++c) acc += a->x[c] * a->W[(size_t)r * a->cols + c];
+        for (size_t blk = 0; blk < nbk; ++blk) {
+            size_t c0 = blk * (size_t)a->block, c1 = c0 + (size_t)a->block > (size_t)a->cols ? (size_t)a->cols : c0 + (size_t)a->block;
+            float scale = sr[blk];
+            for (size_t c = c0; c < c1; ++c) {
+                float wv = tern_value((wr[c / 4] >> ((c % 4) * 2)) & 3u) * scale;
+                acc += a->x[c] * wv;
+            }
+        }
         a->y[r] = acc;
     }
-    return NULL;
 }
-static void dense_mt(const float *W, const float *x, float *y, int rows, int cols, int n_threads) {
-    pthread_t th[64];
-    struct dense_arg args[64];
+static void dense_task(void *p, int t) {
+    const struct dense_arg *a = (const struct dense_arg *)p;
+    int r0 = t * a->per, r1 = r0 + a->per > a->rows ? a->rows : r0 + a->per;
+    if (r0 < r1) dense_rows(a, r0, r1);
+}
+static void dense_mt(struct dense_arg *a, int n_threads) {
     int nt = n_threads > 64 ? 64 : n_threads;
-    int per = (rows + nt - 1) / nt, used = 0;
-    for (int t = 0; t < nt; ++t) {
-        int r0 = t * per, r1 = r0 + per > rows ? rows : r0 + per;
-        if (r0 >= r1) break;
-        args[t] = (struct dense_arg){W, x, y, r0, r1, cols};
-        pthread_create(&th[t], NULL, dense_worker, &args[t]);
-        ++used;
+    if (nt < 2 || a->rows < 256) {
+        dense_rows(a, 0, a->rows);
+        return;
     }
-    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+    a->per = (a->rows + nt - 1) / nt;
+    bo_parallel_for(nt, nt, dense_task, a);
 }
 
 void *bo_model_create(const bo_model_cfg *cfg, int n_threads) {
@@ -289,6 +340,18 @@ int bo_model_set_layer_dense(void *mp, int layer, const float *attn_norm, const 
     return 0;
 }
 
+int bo_model_set_layer_ternary(void *mp, int layer, const float *attn_norm, const float *ffn_norm,
+                               const uint8_t *const *codes7, const float *const *scales7, int block) {
+    bo_model *m = (bo_model *)mp;
+    if (layer < 0 || layer >= m->cfg.n_layers || block < 1) return 1;
+    bo_layer *L = &m->layers[layer];
+    L->attn_norm = attn_norm;
+    L->ffn_norm = ffn_norm;
+    for (int i = 0; i < 7; ++i) L->tern[i] = codes7[i], L->tern_scales[i] = scales7[i];
+    L->tern_block = block;
+    return 0;
+}
+
 void bo_model_set_globals(void *mp, const uint16_t *embed_f16, const float *final_norm) {
     bo_model *m = (bo_model *)mp;
     m->embed_f16 = embed_f16;
@@ -317,17 +380,9 @@ int bo_kv_len(void *p) { return ((bo_kv *)p)->seq_len; }
  * AVX2 when present (Q/i2s_qk256.rs:355-368). */
 static int proj(const bo_model *m, const bo_layer *L, int which, const uint8_t *w, const float *x, float *y, int rows,
                 int cols) {
-    if (L->dense[which]) { /* x . W^T, one f32 dot product per output */
-        const float *W = L->dense[which];
-        if (m->n_threads > 1 && rows >= 256) {
-            dense_mt(W, x, y, rows, cols, m->n_threads);
-            return 0;
-        }
-        for (int r = 0; r < rows; ++r) {
-            float acc = 0.0f;
-            for (int c = 0; c < cols; ++c) acc += x[c] * W[(size_t)r * cols + c];
-            y[r] = acc;
-        }
+    if (L->dense[which] || L->tern[which]) { /* x . W^T, one f32 dot product per output */
+        struct dense_arg a = {L->dense[which], x, L->tern[which], L->tern_scales[which], L->tern_block, y, 0, rows, cols};
+        dense_mt(&a, m->n_threads);
         return 0;
     }
     size_t stride = (size_t)((cols + 255) / 256) * 64;
@@ -343,35 +398,28 @@ struct logit_arg {
     const bo_model *m;
     const float *h;
     float *out;
-    int v0, v1;
+    int per;
 };
-static void *logit_worker(void *p) {
+static void logit_task(void *p, int t) {
     struct logit_arg *a = (struct logit_arg *)p;
-    int H = a->m->cfg.hidden;
-    for (int v = a->v0; v < a->v1; ++v) {
+    int H = a->m->cfg.hidden, V = a->m->cfg.vocab;
+    int v0 = t * a->per, v1 = v0 + a->per > V ? V : v0 + a->per;
+    for (int v = v0; v < v1; ++v) {
         const uint16_t *row = a->m->embed_f16 + (size_t)v * H;
         float acc = 0.0f;
         for (int k = 0; k < H; ++k) acc += a->h[k] * bo_f16_to_f32(row[k]);
         a->out[v] = acc;
     }
-    return NULL;
 }
 
 /* T:1599-1630: logits = hidden . E^T with E the (f16-sourced) embedding matrix */
 void bo_logits(void *mp, const float *hidden, float *logits) {
     bo_model *m = (bo_model *)mp;
     int nt = m->n_threads, V = m->cfg.vocab;
-    pthread_t th[64];
-    struct logit_arg args[64];
     if (nt > 64) nt = 64;
-    int per = (V + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) {
-        int v0 = t * per, v1 = v0 + per > V ? V : v0 + per;
-        if (v0 > V) v0 = V;
-        args[t] = (struct logit_arg){m, hidden, logits, v0, v1};
-        pthread_create(&th[t], NULL, logit_worker, &args[t]);
-    }
-    for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
+    if (nt < 1) nt = 1;
+    struct logit_arg a = {m, hidden, logits, (V + nt - 1) / nt};
+    bo_parallel_for(nt, nt, logit_task, &a);
 }
 
 /* One decode step (T:1482-1504 body): embed -> blocks -> final norm [-> logits].

@@ -319,7 +319,7 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
     dec.feed(prompt[:1024])
     dec.prefill(1024, with_logits=True, digits=2)
     t = hip.matmul_last_tile()  # the last launch of the loop is a 2560-row down-projection: at 1024 rows a narrower tile, and QK256 keeps the
-    assert t["digits"] == 2 and t["scale_mode"] == (0 if fmt == "qk256" else 4)  # int8 planes there (the hybrid forward starts at 3265 tokens)
+    assert t["digits"] == 2 and t["scale_mode"] == (0 if fmt == "qk256" else 4)  # int8 planes there (the hybrid forward starts at 2497 tokens: Decoder::hybrid_applies)
     assert dec.position() == 1024
     c = cosine(dec.last_logits(), o_1k)
     assert c >= 0.9999, c

@@ -258,6 +258,51 @@ def test_f16_handover_flags_of_the_digit_form(hip, torch_):
         hip.weights_free(h)
 
 
+_F16A_SCRIPT = r"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+pkg = importlib.import_module("bitnet-rs_amd")
+hip = pkg.load(); hip.init(0)
+rng = np.random.default_rng(8)
+K, N, m = 1024, 512, 70
+stride = K // 256 * 64
+qa = rng.integers(0, 256, N * stride, dtype=np.uint8)
+ha = hip.weights_upload_qk256(qa, N, K, stride)
+x16 = rng.normal(0, 1, (m, K)).astype(np.float16)
+wsb = hip.matmul_workspace_bytes(m, K, 2)
+ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+ya, yb = torch.empty(m, N, device="cuda"), torch.full((m, N), float("nan"), device="cuda")
+hip.matmul_fused_dev(ha, torch.from_numpy(x16.astype(np.float32)).cuda(), ya, m, ws, wsb, digits=2)
+assert hip.matmul_last_tile()["scale_mode"] == 5, hip.matmul_last_tile()   # k_gemm_f16a, unscaled (the env route was taken)
+hip.matmul_fused_dev(ha, torch.from_numpy(x16).cuda(), yb, m, ws, wsb, digits=2, flags=2)
+assert hip.matmul_last_tile()["scale_mode"] == 5
+torch.cuda.synchronize()
+a, b = ya.cpu().numpy(), yb.cpu().numpy()
+assert np.array_equal(a, b), float(np.max(np.abs(a - b)))
+# and against a float64 product of the same f16 values: one rounding to f16 per element (row maximum in [1, 2)), f32 accumulation
+codes = np.stack([(qa.reshape(N, K // 4) >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(N, K)
+W = np.array([-2.0, -1.0, 1.0, 2.0])[codes]
+want = x16.astype(np.float64) @ W.T
+assert np.max(np.abs(a - want)) <= 2e-3 * np.max(np.abs(want)), float(np.max(np.abs(a - want)))
+print("F16A_X_F16_OK")
+"""
+
+
+def test_x_f16_handover_under_the_f16a_env_route_reads_f16_rows():
+    """with BITNET_HIP_GEMM_F16A=1 an unscaled matrix at 2 digits goes to launch_gemm_f16, whose quantiser
+    k_quant_rows_f16 ignored QuantArgs::x_f16 and read the f16 hand-over rows as f32 (garbage + reads past the allocation).  The
+    switch is read once per process, hence the child process: f16 rows must give, bit for bit, what the same values as f32 rows
+    give, on the f16 kernel (scale_mode 5 asserted)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _F16A_SCRIPT.format(root=root)], env=dict(os.environ, BITNET_HIP_GEMM_F16A="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "F16A_X_F16_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 INT8_DIGITS, FP6_DIGITS = 8, 16  # BITNET_HIP_FUSE_INT8_DIGITS, BITNET_HIP_FUSE_FP6_DIGITS
 
 

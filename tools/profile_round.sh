@@ -42,7 +42,8 @@ for WL in $PASSES; do
         PMC_ARGS="--workload $WL --prompt 8 --steps 8 --warmup 0 --no-cpu-baseline --no-stream --no-exact-check --no-also"
         if [ "$WL" = c4 ]; then PMC_ARGS="--workload c4 --steps 8 --warmup 0 --no-cpu-baseline --no-stream --no-exact-check --layers 4"; fi
         three_passes "$D" python3 bench.py || exit 1
-        python3 bench.py --workload $WL --steps 128 --warmup 8 > "$D/bench.json" 2> "$D/bench.err" || { tail -5 "$D/bench.err"; exit 1; }
+        STEPS=128; if [ "$WL" = c4 ]; then STEPS=512; fi   # configs[3] as written: 4096-token prefill + 512 decode
+        python3 bench.py --workload $WL --steps $STEPS --warmup 8 > "$D/bench.json" 2> "$D/bench.err" || { tail -5 "$D/bench.err"; exit 1; }
         python3 tools/profile_summary.py "$D" "$TAG" "$WL" || exit 1 ;;
     stream)
         for F in i2s qk256; do
