@@ -20,6 +20,20 @@ def _lib():
     raise OSError("librccl.so not found")
 
 
+def version():
+    """ncclGetVersion of the librccl.so this process would use, as "major.minor.patch" (None when the library is absent)."""
+    try:
+        L = _lib()
+        v = C.c_int(0)
+        L.ncclGetVersion.argtypes = [C.POINTER(C.c_int)]
+        if L.ncclGetVersion(C.byref(v)) != 0:
+            return None
+    except (OSError, AttributeError):
+        return None
+    n = v.value
+    return f"{n // 10000}.{n // 100 % 100}.{n % 100}" if n >= 10000 else f"{n // 1000}.{n // 100 % 10}.{n % 100}"
+
+
 class Comm:
     def __init__(self, rank: int, world: int):
         import torch

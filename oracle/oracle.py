@@ -400,6 +400,16 @@ class OracleModel:
             raise OracleError(f"bo_model_step rc={rc}")
         return hid, logits, trace
 
+    def logits(self, hidden) -> np.ndarray:
+        """bo_logits (T:1599-1630): hidden . E^T over the f16-sourced table, rows dealt to this model's host threads."""
+        h, hp = _f32(hidden)
+        out = np.zeros(self.cfg.vocab, np.float32)
+        L = lib()
+        L.bo_logits.argtypes = [C.c_void_p, _f32p, _f32p]
+        L.bo_logits.restype = None
+        L.bo_logits(self.m, hp, out.ctypes.data_as(_f32p))
+        return out
+
     def close(self):
         if self.m:
             lib().bo_kv_destroy(self.kv)
