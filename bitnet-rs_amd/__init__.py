@@ -357,6 +357,10 @@ class HipLib:
         """Output rows per wave of this thread's last tiled matmul: 64, or 80 (320-row workgroups)."""
         return int(self.c.bitnet_hip_matmul_last_wave_rows())
 
+    def matmul_last_resident_fp4(self) -> bool:
+        self.c.bitnet_hip_matmul_last_resident_fp4.restype = C.c_int
+        return bool(self.c.bitnet_hip_matmul_last_resident_fp4())
+
     def attention_prefill_workspace_bytes(self, n_heads: int, n_kv: int, seq_len: int) -> int:
         return int(self.c.bitnet_hip_attention_prefill_workspace_bytes(n_heads, n_kv, seq_len))
 
@@ -412,6 +416,11 @@ class HipLib:
 
     def weights_device_bytes(self, h: int) -> int:
         return int(self.c.bitnet_hip_weights_device_bytes(h))
+
+    def weights_fp4_image(self, h: int, enable: bool = True, stream: int = 0) -> None:
+        """Build (or free) the resident fp4 image the fp6 x fp4 prompt matmul reads (include/bitnet_hip.h)."""
+        self.c.bitnet_hip_weights_fp4_image.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+        self._check(self.c.bitnet_hip_weights_fp4_image(h, 1 if enable else 0, stream))
 
     def weights_trim(self, h: int) -> None:
         self._check(self.c.bitnet_hip_weights_trim(h))

@@ -37,6 +37,7 @@ void free_weights(Weights *w) {
     if (w->codes) (void)hipFree(w->codes);
     if (w->scales) (void)hipFree(w->scales);
     if (w->tiles) (void)hipFree(w->tiles);
+    if (w->tiles4) (void)hipFree(w->tiles4);
     if (w->scale_tiles) (void)hipFree(w->scale_tiles);
     if (w->scale_tiles_h) (void)hipFree(w->scale_tiles_h);
     if (w->ln_g) (void)hipFree(w->ln_g);
@@ -498,6 +499,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
     fu.y_f16 = (flags & BITNET_HIP_FUSE_Y_F16) != 0;
     fu.int8_form = (flags & BITNET_HIP_FUSE_INT8_DIGITS) != 0;
     fu.fp6_form = (flags & BITNET_HIP_FUSE_FP6_DIGITS) != 0;
+    fu.fp6_expand = (flags & BITNET_HIP_FUSE_FP6_EXPAND) != 0;
     if (fu.fp6_form && (fu.int8_form || digits != 2 || !gemm_fp6_supported(*w)))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_FP6_DIGITS needs digits = 2, an unscaled matrix with a code map in -2..2, and no FUSE_INT8_DIGITS");
     if (fu.silu_mul && (!w->paired || residual_dev))
@@ -514,10 +516,32 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t h, const float *x_dev, floa
         pin.reset(new ReferencePin(*w, (hipStream_t)stream, /*scales_only=*/true));
         if (pin->status != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "rebuilding the row-major block scales failed");
     }
+    // the fp6 x fp4 form reads its weights from the resident fp4 image: built here on first use (an allocation + one retile launch:
+    // hosts that capture or time the call build it ahead with bitnet_hip_weights_fp4_image)
+    if (gemm_fp4_resident_enabled() && !fu.fp6_expand && !w->tiles4 && gemm_takes_fp6(*w, fu, digits)) {
+        const hipError_t ei = ensure_fp4_image(*w, (hipStream_t)stream);
+        if (ei != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "building the resident fp4 weight image failed: %s", hipGetErrorString(ei));
+    }
     hipError_t e = launch_gemm_mfma(*w, x_dev, y_dev, m, fu, digits, workspace_dev, workspace_bytes, (hipStream_t)stream);
     if (e == hipErrorInvalidValue && (fu.x_f16 || fu.y_f16))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_X_F16 / FUSE_Y_F16: this matrix runs on the f16 matrix cores at this digit count: use bitnet_hip_matmul_f16_dev");
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_weights_fp4_image(bitnet_hip_weights_t h, int enable, void *stream) {
+    BH_GUARD_BEGIN
+    const WeightsRef w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!enable) {
+        drop_fp4_image(*w);
+        return BITNET_HIP_OK;
+    }
+    if (!gemm_fp6_supported(*w))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "weights_fp4_image: needs an unscaled matrix whose code map lies in -2..2 (the fp6 x fp4 form's matrices)");
+    const hipError_t e = ensure_fp4_image(*w, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "building the resident fp4 weight image failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
     BH_GUARD_END
 }
@@ -578,6 +602,8 @@ int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *
 }
 
 int bitnet_hip_matmul_last_wave_rows(void) { return g_last_gemm_tile.digits ? g_last_gemm_tile.wave_rows : 0; }
+
+int bitnet_hip_matmul_last_resident_fp4(void) { return g_last_gemm_tile.resident_fp4; }
 
 int bitnet_hip_gemv_fused_dev(bitnet_hip_weights_t h, const float *x_dev, float *y_dev, size_t m,
                               const float *ln_gamma_dev, float ln_eps, const float *residual_dev, int flags,

@@ -72,6 +72,8 @@ struct Weights {
     // MFMA layout (built lazily by the MFMA path): 16-row x 256-col tiles,
     // 1 KiB each, lane-ordered.  See kernels_mfma.hip.
     uint8_t *tiles = nullptr;
+    // resident fp4 image for the prompt matmul's fp6 x fp4 form (kernels_gemm.hip k_retile_fp4 / ensure_fp4_image): optional, 4 bits per weight
+    uint8_t *tiles4 = nullptr;
     float *scale_tiles = nullptr;  // 32-block scales in tile order (kernels_mfma.hip k_retile_scales)
     // Every scale is exactly an f16 value (BitNet32-F16 files store them so): the streaming layout
     // keeps them as f16 (2 bytes per 32 weights instead of 4) -- same numbers, fewer bytes.
@@ -96,6 +98,7 @@ struct GemvFusion {
     bool x_f16 = false, y_f16 = false;  // prefill matmul only: x rows / the silu * up output are f16 (BITNET_HIP_FUSE_X_F16 / _Y_F16)
     bool int8_form = false;             // prefill matmul only: keep the int8 digit planes (BITNET_HIP_FUSE_INT8_DIGITS: no fp6 / f16 form)
     bool fp6_form = false;              // prefill matmul only: the fp6 x fp4 form of the 2-digit product (BITNET_HIP_FUSE_FP6_DIGITS)
+    bool fp6_expand = false;            // ... expanding the 2-bit tiles in its K loop instead of reading the resident fp4 image (BITNET_HIP_FUSE_FP6_EXPAND)
     // x = the decode attention's output, merged from its chunk records by the GEMV itself (no combine launch):
     // records of launch_attn_decode(..., combine = false); contexts of at most 4 records
     const float *attn_rec = nullptr;
@@ -167,7 +170,11 @@ struct ReferencePin {
 size_t weights_device_bytes(const Weights &w);
 // many-row (prefill) matmul, kernels_gemm.hip: ndig in {2,3,4} fixed-point digits per activation
 bool gemm_supported(const Weights &w);
-bool gemm_fp6_supported(const Weights &w);  // unscaled, code map in -2 .. 2: the fp6 x fp4 form of the 2-digit product (k_gemm_fp6)
+bool gemm_fp6_supported(const Weights &w);
+bool gemm_fp4_resident_enabled();                            // BITNET_HIP_FP4_RESIDENT != 0 (default on)
+hipError_t ensure_fp4_image(Weights &w, hipStream_t stream);  // builds Weights::tiles4 once (under the handle's mutex)
+void drop_fp4_image(Weights &w);
+bool gemm_takes_fp6(const Weights &w, const GemvFusion &fu, int ndig);  // would launch_gemm_mfma run k_gemm_fp6 for this call?  // unscaled, code map in -2 .. 2: the fp6 x fp4 form of the 2-digit product (k_gemm_fp6)
 bool gemm_needs_row_major_scales(const Weights &w);  // 256-block scales and non-f16 32-block scales: the others read the scale tiles
 size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig);
 // The f16 activation chain of the prompt forward (kernels_gemm.hip k_gemm_f16a<.., 1>): the input is an f16 matrix [m_pad][cols]
@@ -195,6 +202,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
 // weight-scale mode (0 none, 1 per 256-block, 2 masked K = 64 per 32-block, 3 K = 32 MFMA with f16 scale tiles)
 struct GemmTileChoice {
     int digits = 0, wave_tokens = 0, waves = 0, scale_mode = 0, wave_rows = 64;
+    int resident_fp4 = 0;  // the fp6 form read its weight operands from the resident fp4 image
 };
 extern thread_local GemmTileChoice g_last_gemm_tile;
 extern unsigned long long *g_mfma_stamps;  // diagnostic build only

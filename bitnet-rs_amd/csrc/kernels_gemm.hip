@@ -60,6 +60,7 @@ struct GemmArgs {
     const float *gamma_out = nullptr;
     float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
     unsigned long long *stamps = nullptr;  // diagnostic build (BH_STAMPS): per wave 8 x u64 of phase cycles, tools/stamp_f16a.py
+    const uint8_t *tiles4 = nullptr;  // k_gemm_fp6<.., RES = 1>: the resident fp4 image [n_tiles][nblk][m 2][64][16] (k_retile_fp4)
     int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
 
@@ -186,11 +187,12 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
         typedef unsigned qv6u __attribute__((ext_vector_type(6)));
         uint8_t *rbase = reinterpret_cast<uint8_t *>(p.planes) + (size_t)row * (size_t)(p.kp >> 8) * 576;
         uint8_t *orow = reinterpret_cast<uint8_t *>(qrow) + (size_t)(p.kp >> 5) * 144;
-        // one work item = (digit, 32-column unit): all four waves pack (80 units x 3 digits for 2560 columns)
+        // one work item = one 32-column unit, ALL THREE digits (round 5: a work item per (digit, unit) computed the four digit
+        // instructions of every element three times over and kept one: 1,280 wave-instructions per row against ~100 of the int8
+        // split -- the fp6 quantiser took 20 / 40-46 us where the int8 one took 11-17 / 25; now 4 VALU per element, once)
         const int n_units = p.kp >> 5;
-        for (int w = tid; w < 3 * n_units; w += 256) {
-            const int d = w / n_units, u = w - d * n_units;
-            qv16f lo, hi;
+        for (int u = tid; u < n_units; u += 256) {
+            qv16f lo[3], hi[3];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float4 f = *reinterpret_cast<const float4 *>(qrow + (u * 9 + k) * 4);
@@ -199,15 +201,19 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const float r1 = __builtin_rintf(xs[e] * 0.03125f), d0 = __builtin_fmaf(r1, -32.0f, xs[e]);
                     const float r2 = __builtin_rintf(r1 * 0.03125f), d1 = __builtin_fmaf(r2, -32.0f, r1);
-                    const float dv = d == 0 ? d0 : d == 1 ? d1 : r2;
-                    if (k & 1) hi[4 * (k >> 1) + e] = dv;
-                    else lo[4 * (k >> 1) + e] = dv;
+                    const int ix = 4 * (k >> 1) + e;
+                    if (k & 1) hi[0][ix] = d0, hi[1][ix] = d1, hi[2][ix] = r2;
+                    else lo[0][ix] = d0, lo[1][ix] = d1, lo[2][ix] = r2;
                 }
             }
-            const qv6u r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo, hi, 8.0f);
             // the packed row is assembled in LDS (behind the integers) and leaves in whole 16-byte pieces, lane after lane
-            uint2 *o = reinterpret_cast<uint2 *>(orow + (size_t)(u >> 3) * 576 + ((u >> 1) & 3) * 144 + (u & 1) * 24 + d * 48);
-            o[0] = uint2{r[0], r[1]}, o[1] = uint2{r[2], r[3]}, o[2] = uint2{r[4], r[5]};
+            uint8_t *ob = orow + (size_t)(u >> 3) * 576 + ((u >> 1) & 3) * 144 + (u & 1) * 24;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const qv6u r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo[d], hi[d], 8.0f);
+                uint2 *o = reinterpret_cast<uint2 *>(ob + d * 48);
+                o[0] = uint2{r[0], r[1]}, o[1] = uint2{r[2], r[3]}, o[2] = uint2{r[4], r[5]};
+            }
         }
         __syncthreads();
         for (int i = tid; i < (p.kp >> 8) * 36; i += 256) reinterpret_cast<uint4 *>(rbase)[i] = reinterpret_cast<const uint4 *>(orow)[i];
@@ -1122,8 +1128,26 @@ __device__ __forceinline__ void expand16_fp4(uint32_t w, uint32_t lut4, int &o0,
     o1 = (int)((p3 << 4) | p2);  //         elements 8 + b, 12 + b
 }
 
+// The resident fp4 image (round 5): exactly the nibbles expand16_fp4 produces, stored once per matrix -- [row tile][256-block][MFMA m 2]
+// [lane 64][16 B] = 2 KiB per (tile, block), twice the 2-bit streaming tile (which stays the decode path's copy).  k_gemm_fp6<.., RES = 1>
+// loads its A operands straight from it: no code expansion in the K loop (13 VALU per 16 weights and lane before).
+__global__ void k_retile_fp4(const uint8_t *__restrict__ tiles, uint8_t *__restrict__ tiles4, uint32_t lut4, size_t total16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte lane segment of the streaming tiles each
+    if (i >= total16) return;
+    const gv4u w = *reinterpret_cast<const gv4u *>(tiles + i * 16);
+    int e[8];
+    expand16_fp4(w.x, lut4, e[0], e[1]);
+    expand16_fp4(w.y, lut4, e[2], e[3]);
+    expand16_fp4(w.z, lut4, e[4], e[5]);
+    expand16_fp4(w.w, lut4, e[6], e[7]);
+    const size_t tb = i >> 6, lane = i & 63;
+    *reinterpret_cast<v4i *>(tiles4 + ((tb * 2 + 0) * 64 + lane) * 16) = (v4i){e[0], e[1], e[2], e[3]};
+    *reinterpret_cast<v4i *>(tiles4 + ((tb * 2 + 1) * 64 + lane) * 16) = (v4i){e[4], e[5], e[6], e[7]};
+}
+
 // RT = row tiles per wave: 4, or 5 (320-row workgroups: gemm_five_tiles; no silu * mul pairing with it).
-template <int TTW, int RT = 4>
+// RES = 1: A operands from the resident fp4 image (GemmArgs::tiles4) instead of expanding the 2-bit tiles in the loop.
+template <int TTW, int RT = 4, int RES = 0>
 __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {
     constexpr int T = 16 * TTW, UNITS = T * 36, NB = (UNITS + 255) / 256, kBuf = T * 576;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1144,12 +1168,14 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
             }
         }
     }
+    constexpr int NM = RES ? 2 : 1;            // 16-byte weight loads per row tile and K step
+    constexpr size_t WSTEP = RES ? 2048 : 1024;  // bytes of one (tile, 256-block) in the layout read
     const uint8_t *wptr[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         int t = bx * (4 * RT) + rw * RT + rt;
         t = t < n_tiles ? t : n_tiles - 1;
-        wptr[rt] = p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
+        wptr[rt] = RES ? p.tiles4 + ((size_t)t * p.nblk * 128 + lane) * 16 : p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
     }
     // this thread's 16-byte units of the activation tile: unit u of a token's 576 bytes = (g = u / 9, k = u % 9)
     const size_t row_bytes = (size_t)p.nblk * 576;
@@ -1168,9 +1194,11 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
-    gv4u wn[RT], bn[NB];
+    gv4u wn[NM][RT], bn[NB];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt]);
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + m * 1024);
 #pragma unroll
     for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
 #pragma unroll
@@ -1190,13 +1218,17 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
 #pragma unroll
             for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
         }
-        gv4u wc[RT];
+        gv4u wc[NM][RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) wc[rt] = wn[rt];
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) wc[m][rt] = wn[m][rt];
         {
             const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1, n2 = blk + 2 < p.nblk ? blk + 2 : p.nblk - 1;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) wn[rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * 1024);
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * WSTEP + m * 1024);
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 576);
         }
@@ -1213,11 +1245,16 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
         v4i a[2][RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
+            if (RES) {  // the image holds the operands as they are
+                a[0][rt] = __builtin_bit_cast(v4i, wc[0][rt]);
+                a[1][rt] = __builtin_bit_cast(v4i, wc[NM - 1][rt]);
+                continue;
+            }
             int e[8];
-            expand16_fp4(wc[rt].x, lut4, e[0], e[1]);
-            expand16_fp4(wc[rt].y, lut4, e[2], e[3]);
-            expand16_fp4(wc[rt].z, lut4, e[4], e[5]);
-            expand16_fp4(wc[rt].w, lut4, e[6], e[7]);
+            expand16_fp4(wc[0][rt].x, lut4, e[0], e[1]);
+            expand16_fp4(wc[0][rt].y, lut4, e[2], e[3]);
+            expand16_fp4(wc[0][rt].z, lut4, e[4], e[5]);
+            expand16_fp4(wc[0][rt].w, lut4, e[6], e[7]);
             a[0][rt] = (v4i){e[0], e[1], e[2], e[3]};
             a[1][rt] = (v4i){e[4], e[5], e[6], e[7]};
         }
@@ -1491,6 +1528,45 @@ int gemm_fp6_mode() {
 }
 bool gemm_fp6_supported(const Weights &w) { return gemm_supported(w) && !w.scaled && lut_fits_f16w(w.lut); }
 
+// ---- the resident fp4 image of a matrix (Weights::tiles4): built once (at upload when the host asks: bitnet_hip_weights_fp4_image; else by the
+// first fp6-form launch), under the handle's mutex; 4 bits per weight beside the 2-bit streaming tiles, which stay the decode path's copy.
+// BITNET_HIP_FP4_RESIDENT=0 keeps the in-loop expansion (no image is ever built).
+bool gemm_fp4_resident_enabled() {
+    static const int mode = [] { const char *e = getenv("BITNET_HIP_FP4_RESIDENT"); return e ? atoi(e) : 1; }();
+    return mode != 0;
+}
+hipError_t ensure_fp4_image(Weights &w, hipStream_t stream) {
+    if (!gemm_fp6_supported(w)) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(*w.mu);
+    if (w.tiles4) return hipSuccess;
+    const size_t n_tiles = div_ceil(w.rows, 16), nblk = div_ceil(w.cols, 256), total16 = n_tiles * nblk * 64;
+    uint8_t *img = nullptr;
+    hipError_t e = hipMalloc((void **)&img, total16 * 32);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_retile_fp4, dim3((unsigned)div_ceil(total16, 256)), dim3(256), 0, stream, w.tiles, img, lut_fp4(w.lut), total16);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // other threads / streams may launch on the image the moment the lock is gone
+    if (e != hipSuccess) {
+        (void)hipFree(img);
+        return e;
+    }
+    w.tiles4 = img;
+    return hipSuccess;
+}
+void drop_fp4_image(Weights &w) {
+    std::lock_guard<std::mutex> lk(*w.mu);
+    if (w.tiles4) (void)hipFree(w.tiles4);
+    w.tiles4 = nullptr;
+}
+// would launch_gemm_mfma send this call to k_gemm_fp6? (the ABI asks before the launch, to build the image outside it)
+bool gemm_takes_fp6(const Weights &w, const GemvFusion &fu, int ndig) {
+    if (fu.int8_form || ndig != 2 || !gemm_fp6_supported(w)) return false;
+    if (gemm_k32(w)) return false;
+    static const int f16a_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16A"); return e ? atoi(e) : 0; }();
+    if (f16a_mode && w.cols % 256 == 0) return false;
+    return fu.fp6_form || gemm_fp6_mode();
+}
+
 static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
     const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<2, 3, 1> : k_quant_rows<2, 8, 1>;
@@ -1500,7 +1576,9 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     const bool rt5 = ttw == 4 && !a.silu_mul && w.rows % 4 == 0 && gemm_five_tiles(w.rows, q.m_pad);
     if (rt5) gx0 = w.rows / 320;
     else ttw = gemm_token_tiles(gx0, q.m_pad, true);
-    void (*fk)(GemmArgs, uint32_t) = rt5 ? k_gemm_fp6<4, 5> : ttw == 4 ? k_gemm_fp6<4> : ttw == 2 ? k_gemm_fp6<2> : k_gemm_fp6<1>;
+    const bool res = a.tiles4 != nullptr;
+    void (*fk)(GemmArgs, uint32_t) = res ? (rt5 ? k_gemm_fp6<4, 5, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 1> : k_gemm_fp6<1, 4, 1>)
+                                         : (rt5 ? k_gemm_fp6<4, 5> : ttw == 4 ? k_gemm_fp6<4> : ttw == 2 ? k_gemm_fp6<2> : k_gemm_fp6<1>);
     {
         static std::mutex f_mu;
         static std::unordered_set<const void *> f_raised;
@@ -1511,8 +1589,10 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
             f_raised.insert((const void *)fk);
         }
     }
-    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 6, rt5 ? 80 : 64};
-    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, a, lut_fp4(w.lut));
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 6, rt5 ? 80 : 64, res ? 1 : 0};
+    GemmArgs aw = a;
+    aw.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);  // (the image is twice the bytes per row block)
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, aw, lut_fp4(w.lut));
     return hipGetLastError();
 }
 
@@ -1623,6 +1703,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
     a.residual = fu.residual;
     a.wscale = k32 ? nullptr : w.scales;  // per 256-block or per 32-block (row-major [rows, cols / block])
     a.silu_mul = fu.silu_mul ? 1 : 0;
+    a.tiles4 = gemm_fp4_resident_enabled() && !fu.fp6_expand ? w.tiles4 : nullptr;  // (set before the launch by the ABI: ensure_fp4_image)
     const bool takes_f16 = !fu.int8_form && ndig == 2 && k32 && lut_fits_f16w(w.lut) && w.scales_f16_x2_finite;
     if (fu.x_f16 || fu.y_f16) {  // f16 hand-over: the int8 digit form's quantiser reads f16 rows; silu * up goes out as f16 rows
         const bool f16_form = takes_f16;
@@ -1635,7 +1716,7 @@ hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m
         if (f16a_mode && ndig == 2 && !w.scaled && lut_fits_f16w(w.lut) && w.cols % 256 == 0)
             return launch_gemm_f16(w, q, a, stream);
         // unscaled matrices at 2 digits: the same integer on the fp6 x fp4 MFMA, on request (flag) or by BITNET_HIP_GEMM_FP6=1
-        if (ndig == 2 && (fu.fp6_form || gemm_fp6_mode()) && gemm_fp6_supported(w)) return launch_gemm_fp6(w, q, a, stream);
+        if (gemm_takes_fp6(w, fu, ndig)) return launch_gemm_fp6(w, q, a, stream);
     }
     if (ndig == 2) return launch_gemm_t<2, 4>(w, q, a, stream);
     if (ndig == 3) return launch_gemm_t<3, 2>(w, q, a, stream);

@@ -835,6 +835,7 @@ size_t weights_device_bytes(const Weights &w) {
     if (w.codes) b += w.rows * w.row_stride_bytes;
     if (w.scales) b += w.rows * w.nblk * sizeof(float);
     if (w.tiles) b += n_tiles * nblk * 1024;
+    if (w.tiles4) b += n_tiles * nblk * 2048;
     if (w.scale_tiles) b += n_tiles * nblk * 128 * sizeof(float);
     if (w.scale_tiles_h) b += n_tiles * nblk * 128 * sizeof(uint16_t);
     if (w.ln_g) b += w.rows * sizeof(float);

@@ -752,6 +752,30 @@ bool Decoder::handover16_applies(int digits) const {
     return c_.ffn % 4 == 0;
 }
 
+// q|k|v and gate|up of the digit-plane prompt forward (unscaled matrices, digits = 2) on the block-scaled fp6 x fp4 MFMA reading RESIDENT fp4 images
+// (bitnet_hip_weights_fp4_image: built here once per model, 22.6 MB per layer at the 2B-4T widths; the 2-bit tiles stay the decode copy) -- the
+// same integers as the int8 planes, bit for bit, with no code expansion in the K loop.  BITNET_HOST_PREFILL_FP6=0 keeps the int8 planes.
+int Decoder::fp6_flag(int digits) {
+    if (digits != 2 || layers_.empty()) return 0;
+    if (prefill_fp6_ < 0) {
+        const char *e = getenv("BITNET_HOST_PREFILL_FP6");
+        prefill_fp6_ = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+        for (const auto &L : layers_) {
+            if (!prefill_fp6_) break;
+            for (bitnet_hip_weights_t h : {L.qkv, L.gateup})
+                if (!h || bitnet_hip_weights_fp4_image(h, 1, stream_) != 0) {  // scaled / other code maps: the form does not apply to this model
+                    prefill_fp6_ = 0;
+                    break;
+                }
+        }
+        if (!prefill_fp6_)
+            for (const auto &L : layers_)
+                for (bitnet_hip_weights_t h : {L.qkv, L.gateup})
+                    if (h) (void)bitnet_hip_weights_fp4_image(h, 0, stream_);
+    }
+    return prefill_fp6_ ? BITNET_HIP_FUSE_FP6_DIGITS : 0;
+}
+
 // (Decoder::prefill explains; BITNET_HOST_PREFILL_HYBRID=0 keeps the int8 digit planes for all four projections, =2 takes the f16 form at
 // any length.)  Only for long shares -- where the hidden-row launches of 64-token tiles come to 400 workgroups or more (from 2497 tokens at
 // hidden 2560: 40 token tiles x 10 row blocks): measured, QK256, same box -- 4096 tokens 21.5 -> 20.3 ms, 3072 tokens 17.3 -> 16.4, 8192 tokens 45.3 -> 43.4, but 2048
@@ -875,9 +899,10 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     // matrix cores as they stand (k_gemm_f16a, 320-row workgroups: one round of the chip at 4096 tokens) -- no quantiser launch, no second
     // rounding of values that were rounded to f16 already; q|k|v and gate|up keep the faster int8 digit planes behind their LayerNorm.
     const bool hybrid = h16 && hybrid_applies(N);
+    const int f6 = chain ? 0 : fp6_flag(digits);
     for (auto &L : layers_) {
         if (chain) break;
-        BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+        BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, f6, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         if (h16) {
             BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,
                                                         (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_atth_,
@@ -886,7 +911,7 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
                 BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
             else
                 BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
-            BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, (float *)pf_hh_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | BITNET_HIP_FUSE_Y_F16, digits,
+            BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, (float *)pf_hh_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | BITNET_HIP_FUSE_Y_F16 | f6, digits,
                                              pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             if (hybrid)
                 BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
@@ -901,7 +926,7 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
             BCHK(bitnet_hip_attention_prefill_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
                                                   (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_att_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.o, pf_att_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
-        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL, digits, pf_gemm_ws_,
+        BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | f6, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
     }

@@ -117,6 +117,7 @@ class Decoder {
     bool chain_applies(int digits) const;
     bool handover16_applies(int digits) const;
     bool hybrid_applies(size_t n_rows) const;
+    int fp6_flag(int digits);  // BITNET_HIP_FUSE_FP6_DIGITS for the q|k|v and gate|up launches of the digit-plane prompt forward, or 0
     int ensure_chain_buffers(size_t N);
     int prefill_chain_layers(size_t N);
     void set_phase_timing(bool on) { sp_timing_ = on; }
@@ -212,6 +213,7 @@ class Decoder {
     int pfc_cap_ = 0;
     void *pf_xh_ = nullptr, *pf_atth_ = nullptr, *pf_hh_ = nullptr;
     float *pf_stats_ = nullptr;
+    int prefill_fp6_ = -1;    // BITNET_HOST_PREFILL_FP6: -1 not yet decided, 0 int8 digit planes, 1 the fp6 x fp4 form on resident fp4 images (fp6_flag)
     int prefill_chain_ = -1;  // BITNET_HOST_PREFILL_CHAIN: -1 automatic (the block-scaled format, whose matmul runs on f16 activations anyway), 0 off, 1 on
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;
     size_t weight_bytes_ = 0;

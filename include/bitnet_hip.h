@@ -225,11 +225,14 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
  *     activation as three base-32 digits on the block-scaled fp6 x fp4 MFMA (k_gemm_fp6: same products, f32 accumulation of exact
  *     integers -- bit-identical to the int8 form while every partial sum stays below 2^24); also the process default with
  *     BITNET_HIP_GEMM_FP6=1.  Measured: 10-14 % faster per gate|up / down launch under sustained load, its quantiser 9-20 us slower
- *     per launch: about even inside a prompt, hence opt-in */
+ *     per launch: about even inside a prompt, hence opt-in.  Round 5: the weight operands come from the resident fp4 image
+ *     (bitnet_hip_weights_fp4_image, built on first use) unless
+ *   BITNET_HIP_FUSE_FP6_EXPAND is set too: the fp6 form expanding the 2-bit streaming tiles in its K loop (no image is built or read) */
 #define BITNET_HIP_FUSE_X_F16 2
 #define BITNET_HIP_FUSE_Y_F16 4
 #define BITNET_HIP_FUSE_INT8_DIGITS 8
 #define BITNET_HIP_FUSE_FP6_DIGITS 16
+#define BITNET_HIP_FUSE_FP6_EXPAND 32
 size_t bitnet_hip_matmul_workspace_bytes(size_t m, size_t k, int digits);
 int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, float *y_dev, size_t m,
                                 const float *ln_gamma_dev, float ln_eps, const float *residual_dev,
@@ -245,6 +248,17 @@ int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *
  * f32 accumulators take when they need fewer rounds of the chip -- 2560 output rows x 4096 tokens = 512 workgroups, one round);
  * 0 before the thread's first tiled matmul.  scale_mode 5 = the f16 MFMA on an unscaled matrix, 6 = the fp6 x fp4 form (k_gemm_fp6). */
 int bitnet_hip_matmul_last_wave_rows(void);
+/* 1 when that launch was the fp6 x fp4 form reading its weight operands from the resident fp4 image (below), else 0. */
+int bitnet_hip_matmul_last_resident_fp4(void);
+/* The resident fp4 image of an unscaled matrix whose code map lies in -2..2 (QK256: every value is exact in fp4 e2m1): 4 bits per
+ * weight in the fp6 x fp4 MFMA's A-operand order, kept BESIDE the 2-bit streaming tiles (which remain the decode path's copy:
+ * bitnet_hip_weights_device_bytes counts both; QK256 2B-4T: q|k|v + gate|up of 30 layers = 678 MB, all seven projections 1.04 GB --
+ * HBM is 288 GB).  With it bitnet_hip_matmul_fused_dev's BITNET_HIP_FUSE_FP6_DIGITS form loads its weight operands directly: no code
+ * expansion in the K loop; the integers multiplied are the same, so the results stay bit-identical to the int8 digit planes.
+ * enable = 1 builds it (idempotent; an allocation + one kernel, synchronises `stream`), 0 frees it.  Without this call the first
+ * fp6-form launch on the handle builds it (not under stream capture); BITNET_HIP_FP4_RESIDENT=0 disables the image altogether.
+ * Replaces nothing in the reference: its loader keeps one packed copy (crates/bitnet-quantization/src/i2s_qk256.rs:66-128). */
+int bitnet_hip_weights_fp4_image(bitnet_hip_weights_t h, int enable, void *stream);
 
 /* The prompt forward's f16 ACTIVATION CHAIN (north_star: "2-bit weight unpack x f16 activation dot product"; replaces the reference's
  * per-row loop T:683-691 / T:924 over many activation rows, K/cpu/quantized_matmul.rs:57-96 for the scaled format): every projection

@@ -339,6 +339,39 @@ def test_fp6_form_is_the_int8_two_digit_product_bit_for_bit(hip, oracle, torch_,
     hip.weights_free(h)
 
 
+FP6_EXPAND = 32  # BITNET_HIP_FUSE_FP6_EXPAND
+
+
+@pytest.mark.parametrize("rows,cols,m", [(2560, 2560, 4096), (512, 1024, 70), (13824, 2560, 300), (336, 512, 33)])
+def test_fp6_form_on_the_resident_fp4_image_is_the_expanding_form_bit_for_bit(hip, torch_, rows, cols, m):
+    """Round 5: k_gemm_fp6<.., RES = 1> loads its A operands from the resident fp4 image (k_retile_fp4: exactly the nibbles expand16_fp4
+    produces, stored once) -- the SAME operands, so the same bits as the in-loop expansion (BITNET_HIP_FUSE_FP6_EXPAND) and as the int8
+    planes; the image is 4 bits per weight beside the 2-bit tiles (device bytes asserted), built once, freed on request."""
+    rng = np.random.default_rng(rows + 3 * cols + m)
+    stride = -(-cols // 256) * 64
+    qs = rng.integers(0, 256, rows * stride, dtype=np.uint8)
+    x = (rng.normal(0.1, 1.0, (m, cols)) * np.exp(rng.uniform(-3, 3, (m, 1)))).astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, cols) / 80).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    h = hip.weights_upload_qk256(qs, rows, cols, stride)
+    b0 = hip.weights_device_bytes(h)
+    ye = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS | FP6_EXPAND, ln_gamma=gd, ln_eps=1e-5)
+    assert hip.matmul_last_tile()["scale_mode"] == 6 and not hip.matmul_last_resident_fp4()
+    assert hip.weights_device_bytes(h) == b0  # the expanding form builds nothing
+    yr = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS, ln_gamma=gd, ln_eps=1e-5)  # first use builds the image
+    assert hip.matmul_last_tile()["scale_mode"] == 6 and hip.matmul_last_resident_fp4()
+    tiles = -(-rows // 16) * (stride // 64)
+    assert hip.weights_device_bytes(h) == b0 + tiles * 2048
+    y8 = run_gemm(hip, torch_, h, x, rows, 2, flags=INT8_DIGITS, ln_gamma=gd, ln_eps=1e-5)
+    assert not np.isnan(yr).any()
+    assert np.array_equal(ye, yr) and np.array_equal(y8, yr)
+    hip.weights_fp4_image(h, True)   # idempotent
+    assert hip.weights_device_bytes(h) == b0 + tiles * 2048
+    hip.weights_fp4_image(h, False)
+    assert hip.weights_device_bytes(h) == b0
+    hip.weights_free(h)
+
+
 def test_fp6_form_silu_handover_and_refusals(hip, torch_):
     """The fp6 form with the silu * mul epilogue and the f16 hand-over flags, against the int8 planes bit for bit; refused (never
     silently replaced) where it does not apply: other digit counts, together with FUSE_INT8_DIGITS, matrices with block scales (the
