@@ -299,6 +299,11 @@ __device__ __forceinline__ void store_out4(float *dst, float a, float b, float c
     __builtin_nontemporal_store((gv4f){a, b, c, d}, reinterpret_cast<gv4f *>(dst));
 }
 
+// silu(gate) * up (FeedForward::forward T:756-781, silu(v) = v / (1 + exp(-v))) as the decode GEMV's epilogue computes it (kernels_gemvq.hip):
+// v_exp_f32 + v_rcp_f32, 6 VALU per output.  The IEEE division and libm expf of the first version were ~22 VALU per output: 700 of the ~1400
+// VALU instructions of a gate|up wave's epilogue, which no MFMA of that wave overlaps.  |error| ~ 1e-6 relative (the f16 hand-over rounds at 5e-4).
+__device__ __forceinline__ float gsilu_mul(float gv, float uv) { return gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)) * uv; }
+
 // The epilogue's stores.  A lane (c = token of its 16-token group, g) holds val[rt][j] = output row 16 (tile0 + rt) + 4 g + j of its
 // token: one row tile is 64 contiguous bytes per token, so a store instruction per row tile writes HALF lines (non-temporal, not
 // merged in L2: WRITE_SIZE read 158 MB for 113 MB of gate|up outputs).  Row tiles are therefore stored in PAIRS: the odd tile's values
@@ -354,7 +359,7 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                r[pr][j] = gv / (1.0f + expf(-gv)) * uv;
+                r[pr][j] = gsilu_mul(gv, uv);
             }
         const int ra = 16 * (tile0 >> 1) + 4 * g;  // tile0 / 2 = the wave's first tile of the [m, rows / 2] output
         if (p.yh) {  // f16 rows for the down-projection's quantiser: half the bytes written here and read there (half_rows % 4 == 0 checked by the launcher)
@@ -875,7 +880,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float gv = val[2 * pr][j], uv = val[2 * pr + 1][j];
-                    r[j] = gv / (1.0f + expf(-gv)) * uv;
+                    r[j] = gsilu_mul(gv, uv);
                 }
                 if (live) {
                     if (p.yh) {
@@ -1572,10 +1577,11 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<2, 3, 1> : k_quant_rows<2, 8, 1>;
     hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), (size_t)(q.kp / 32) * 144 + (size_t)(q.kp / 256) * 576, stream, q);  // LDS: the row's integers (144 bytes per 32 columns) + its packed image
     size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
-    int ttw = gemm_token_tiles(gx0, q.m_pad, false);
+    static const size_t cover = [] { const char *e = getenv("BITNET_HIP_FP6_COVER"); return e ? (size_t)atoi(e) : 2 * kGemmCUs; }();  // (developer sweep of the token tile)
+    int ttw = gemm_token_tiles(gx0, q.m_pad, false, cover);
     const bool rt5 = ttw == 4 && !a.silu_mul && w.rows % 4 == 0 && gemm_five_tiles(w.rows, q.m_pad);
     if (rt5) gx0 = w.rows / 320;
-    else ttw = gemm_token_tiles(gx0, q.m_pad, true);
+    else ttw = gemm_token_tiles(gx0, q.m_pad, true, cover);
     const bool res = a.tiles4 != nullptr;
     void (*fk)(GemmArgs, uint32_t) = res ? (rt5 ? k_gemm_fp6<4, 5, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 1> : k_gemm_fp6<1, 4, 1>)
                                          : (rt5 ? k_gemm_fp6<4, 5> : ttw == 4 ? k_gemm_fp6<4> : ttw == 2 ? k_gemm_fp6<2> : k_gemm_fp6<1>);

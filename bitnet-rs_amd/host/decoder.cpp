@@ -900,6 +900,8 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     // rounding of values that were rounded to f16 already; q|k|v and gate|up keep the faster int8 digit planes behind their LayerNorm.
     const bool hybrid = h16 && hybrid_applies(N);
     const int f6 = chain ? 0 : fp6_flag(digits);
+    static const int f6od_env = getenv("BITNET_HOST_PREFILL_FP6_OD") ? atoi(getenv("BITNET_HOST_PREFILL_FP6_OD")) : 0;  // experiment: o / down on the fp6 form too (non-hybrid)
+    const int f6od = f6od_env ? f6 : 0;
     for (auto &L : layers_) {
         if (chain) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, f6, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
@@ -910,13 +912,13 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
             if (hybrid)
                 BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
             else
-                BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+                BCHK(bitnet_hip_matmul_fused_dev(L.o, (const float *)pf_atth_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16 | f6od, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, (float *)pf_hh_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | BITNET_HIP_FUSE_Y_F16 | f6, digits,
                                              pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             if (hybrid)
                 BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
             else
-                BCHK(bitnet_hip_matmul_fused_dev(L.down, (const float *)pf_hh_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+                BCHK(bitnet_hip_matmul_fused_dev(L.down, (const float *)pf_hh_, pf_x_, N, nullptr, 0.f, pf_x_, BITNET_HIP_FUSE_X_F16 | f6od, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
             continue;
         }
         if (kv_f16_)
