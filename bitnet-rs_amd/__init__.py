@@ -341,6 +341,26 @@ class HipLib:
         self._check(self.c.bitnet_hip_matmul_f16_dev(h, _ptr(xh), m, _optr(stats_in), n_stats, _optr(ln_gamma), ln_eps, _optr(y), _optr(residual), flags,
                                                      _optr(yh), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
+    # ---- QB32: producer-quantised rows for the fp6 x fp4 prompt matmul (include/bitnet_hip.h) ----
+    def qb32_bytes(self, m: int, cols: int) -> int:
+        self.c.bitnet_hip_qb32_bytes.restype = _sz
+        self.c.bitnet_hip_qb32_bytes.argtypes = [_sz, _sz]
+        return int(self.c.bitnet_hip_qb32_bytes(m, cols))
+
+    def rows_to_qb32_dev(self, x, gamma, m: int, cols: int, qb, stats, stream: int = 0) -> None:
+        self.c.bitnet_hip_rows_to_qb32_dev.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp, _vp]
+        self._check(self.c.bitnet_hip_rows_to_qb32_dev(_ptr(x), _optr(gamma), m, cols, _ptr(qb), _optr(stats), _vp(stream)))
+
+    def matmul_qb32_supported(self, h: int) -> bool:
+        self.c.bitnet_hip_matmul_qb32_supported.argtypes = [C.c_uint64]
+        return bool(self.c.bitnet_hip_matmul_qb32_supported(h))
+
+    def matmul_qb32_dev(self, h: int, qb, m: int, stats_in=None, n_stats: int = 0, ln_gamma=None, ln_eps: float = 0.0, y=None, residual=None,
+                        flags: int = 0, yh=None, gamma_out=None, stats_out=None, stream: int = 0) -> None:
+        self.c.bitnet_hip_matmul_qb32_dev.argtypes = [C.c_uint64, _vp, _sz, _vp, _sz, _vp, C.c_float, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
+        self._check(self.c.bitnet_hip_matmul_qb32_dev(h, _ptr(qb), m, _optr(stats_in), n_stats, _optr(ln_gamma), ln_eps, _optr(y), _optr(residual), flags,
+                                                      _optr(yh), _optr(gamma_out), _optr(stats_out), _vp(stream)))
+
     def attention_prefill_flags_dev(self, qkv, rope_sin, rope_cos, kcache, vcache, n_heads, n_kv, head_dim, max_pos, seq_len, workspace, workspace_bytes,
                                     out, flags: int, stream: int = 0) -> None:
         self.c.bitnet_hip_attention_prefill_flags_dev.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, C.c_int, _vp]

@@ -584,9 +584,70 @@ int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t h, const void *xh_dev, size_t
     io.yh = yh_dev;
     io.gamma_out = gamma_out_dev;
     io.stats_out = stats_out_dev;
+    if (flags & BITNET_HIP_FUSE_YH_QB32) {  // yh_dev is a QB32 buffer (bitnet_hip_qb32_bytes(m, rows)): the next fp6-form matmul's input
+        if (!yh_dev || io.silu_mul || w->rows % 256 != 0)
+            return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_YH_QB32 needs a QB32 buffer in yh_dev, rows %% 256 == 0 and no FUSE_SILU_MUL");
+        io.qb_out = yh_dev;
+        io.yh = nullptr;
+    }
     if (io.silu_mul && (!w->paired || residual_dev))
         return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
     hipError_t e = launch_gemm_f16_chain(*w, io, m, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue && io.qb_out)
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_YH_QB32: this launch does not run 64-token tiles (too few rows for the QB32 hand-over)");
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+size_t bitnet_hip_qb32_bytes(size_t m, size_t cols) { return qb32_bytes(m, cols); }
+
+int bitnet_hip_rows_to_qb32_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *qb_dev, float *stats_dev, void *stream) {
+    BH_GUARD_BEGIN
+    if (!x_dev || !qb_dev) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to rows_to_qb32_dev");
+    if (m == 0 || cols == 0 || cols % 256 != 0 || cols > 8192) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "rows_to_qb32_dev: m > 0 and cols a multiple of 256 up to 8192, got m=%zu cols=%zu", m, cols);
+    hipError_t e = launch_rows_to_qb32(x_dev, gamma_dev, m, cols, qb_dev, stats_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
+    return BITNET_HIP_OK;
+    BH_GUARD_END
+}
+
+int bitnet_hip_matmul_qb32_supported(bitnet_hip_weights_t h) {
+    const WeightsRef w = lookup(h);
+    return w && gemm_qb32_supported(*w) ? 1 : 0;
+}
+
+int bitnet_hip_matmul_qb32_dev(bitnet_hip_weights_t h, const void *qb_dev, size_t m, const float *stats_in_dev, size_t n_stats,
+                               const float *ln_gamma_dev, float ln_eps, float *y_dev, const float *residual_dev, int flags, void *yh_dev,
+                               const float *gamma_out_dev, float *stats_out_dev, void *stream) {
+    BH_GUARD_BEGIN
+    const WeightsRef w = lookup(h);
+    if (!w) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "unknown weights handle %llu", (unsigned long long)h);
+    if (!qb_dev || (!y_dev && !yh_dev)) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "Null pointer passed to matmul_qb32_dev");
+    if (m == 0) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "dimensions must be > 0: m=0");
+    if (!gemm_qb32_supported(*w))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "matmul_qb32_dev: needs an unscaled matrix with a code map in -2..2, rows %% 256 == 0, cols %% 256 == 0");
+    if ((ln_gamma_dev != nullptr) != (stats_in_dev != nullptr) || (ln_gamma_dev && (!w->ln_g || w->ln_gamma_bound != ln_gamma_dev || n_stats == 0)))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "matmul_qb32_dev: LayerNorm needs the bound gamma (bitnet_hip_weights_bind_ln) and its statistics partials");
+    if (flags & ~BITNET_HIP_FUSE_SILU_MUL) return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "matmul_qb32_dev: unknown flag bits 0x%x", flags);
+    GemmF16Io io;
+    io.xh = qb_dev;
+    io.stats_in = stats_in_dev;
+    io.n_stats = (int)n_stats;
+    io.ln_eps = ln_eps;
+    io.y = y_dev;
+    io.residual = residual_dev;
+    io.silu_mul = (flags & BITNET_HIP_FUSE_SILU_MUL) != 0;
+    io.yh = yh_dev;
+    io.gamma_out = gamma_out_dev;
+    io.stats_out = stats_out_dev;
+    if (io.silu_mul && (!w->paired || residual_dev))
+        return set_error(BITNET_HIP_ERR_INVALID_ARGUMENT, "FUSE_SILU_MUL needs a handle from weights_concat(..., interleave16=1) and no residual");
+    if (gemm_fp4_resident_enabled() && !w->tiles4) {
+        const hipError_t ei = ensure_fp4_image(*w, (hipStream_t)stream);
+        if (ei != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "building the resident fp4 weight image failed: %s", hipGetErrorString(ei));
+    }
+    hipError_t e = launch_gemm_qb32(*w, io, m, (hipStream_t)stream);
     if (e != hipSuccess) return set_error(BITNET_HIP_ERR_GPU, "kernel launch failed: %s", hipGetErrorString(e));
     return BITNET_HIP_OK;
     BH_GUARD_END

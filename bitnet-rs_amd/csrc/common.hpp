@@ -192,7 +192,14 @@ struct GemmF16Io {
     void *yh = nullptr;               // f16 [m_pad][rows] (rows / 2 with silu_mul), nullable
     const float *gamma_out = nullptr; // [rows]: yh = f16(gamma_out * y)
     float *stats_out = nullptr;       // float2 [rows / 64][m_pad]
+    void *qb_out = nullptr;           // QB32 buffer (qb32_bytes(m, rows)) receiving gamma_out * y (launch_gemm_f16_chain only; not with silu_mul)
 };
+// QB32 activation rows (kernels_gemm.hip): digit records [m_pad][cols / 256][576] then one exponent byte per (token, 32 columns); m_pad = m up to 64
+size_t qb32_bytes(size_t m, size_t cols);
+hipError_t launch_rows_to_qb32(const float *x, const float *gamma, size_t m, size_t cols, void *qb, float *stats, hipStream_t stream);
+bool gemm_qb32_supported(const Weights &w);
+// the fp6 x fp4 form on QB32 rows (io.xh = the QB32 buffer) with the f16 chain's epilogue (LayerNorm after the product, residual, silu * up -> f16 rows)
+hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream);
 bool gemm_f16_chain_supported(const Weights &w);
 hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream);
 hipError_t launch_rows_to_f16(const float *x, const float *gamma, size_t m, size_t cols, void *xh, float *stats, hipStream_t stream);

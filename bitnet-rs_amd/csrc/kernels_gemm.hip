@@ -60,6 +60,12 @@ struct GemmArgs {
     const float *gamma_out = nullptr;
     float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
     unsigned long long *stamps = nullptr;  // diagnostic build (BH_STAMPS): per wave 8 x u64 of phase cycles, tools/stamp_f16a.py
+    // ---- QB32 activations (round 5; k_gemm_fp6<.., EPI = 1> consumes, f16_chain_epilogue<.., QB = true> / k_rows_to_qb32 produce): `planes` = the digit
+    // records [m_pad][nblk][576] (the fp6 form's layout), one E8M0-ready exponent byte per (token, 32-column unit) beside them ----------------------------
+    const uint8_t *qb_exps = nullptr;  // [m_pad][nblk * 8]
+    uint8_t *qb_out = nullptr;         // producer: digit records of the OUTPUT rows [m_pad][qb_nblk_out][576] (gamma_out * y, the next matmul's K = rows)
+    uint8_t *qb_exps_out = nullptr;    // [m_pad][qb_nblk_out * 8]
+    int qb_nblk_out = 0;
     const uint8_t *tiles4 = nullptr;  // k_gemm_fp6<.., RES = 1>: the resident fp4 image [n_tiles][nblk][m 2][64][16] (k_retile_fp4)
     int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
@@ -819,9 +825,95 @@ __device__ __forceinline__ gh8 expand8_f16(uint32_t w, int h, uint32_t lut_hi, g
     return (gh8){w2[0][0], w2[0][1], w2[1][0], w2[1][1], w2[2][0], w2[2][1], w2[3][0], w2[3][1]};
 }
 
+// ================================================================================================================================
+// QB32: block-scaled fixed-point activation rows for the fp6 x fp4 prompt matmul, written by the PRODUCER of the activations (round 5).
+// The row quantiser of the digit forms needs the row maximum -- a value no producing workgroup has -- so it stayed a launch of its own
+// (two per layer, 20 us each at 4096 tokens: 6 % of the QK256 prompt).  The scaled MFMA takes one E8M0 scale per lane = per 32 K-slots of
+// one token, so the scale can be LOCAL: per 32-column unit u of a token, E_u = exponent of the unit's largest |v|, q = rint(v 2^(13 - E_u))
+// (|q| <= 2^14: the same 15-bit integer class as the 2-digit planes and as the decode path's QAct, which scales per 16 columns), written as
+// three balanced base-32 digits in fp6 exactly as k_quant_rows<2, NV, 1> writes them; the unit's byte s_u = E_u + 117 + 5 d is the MFMA's
+// scale operand for digit d (2^(s - 127) * n / 8 = 2^(E_u - 13 + 5 d) n).  Products are exact; the f32 accumulator rounds across units of
+// different exponents (2^-24 relative per addition, as every f32-accumulating form here).  LayerNorm is applied AFTER the product, as on the
+// f16 chain: the producer multiplies by the consumer's gamma and leaves (sum, sum of squares) partials of the exact f32 row.
+// One work item packs one unit: 32 f32 values from LDS (eight 16-byte pieces of a 144-byte slot: the ninth piece pads the slot so that
+// sixteen lanes reading sixteen slots touch sixteen different bank groups) -> 3 x 24 bytes of digits at dst + 48 d, returns s_u (d = 0).
+__device__ __forceinline__ uint32_t qb32_pack_unit(const float *src, uint8_t *dst) {
+    typedef float qv16f __attribute__((ext_vector_type(16)));
+    typedef unsigned qv6u __attribute__((ext_vector_type(6)));
+    float4 f[8];
+    float am = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f[k] = *reinterpret_cast<const float4 *>(src + 4 * k);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(f[k].x), fabsf(f[k].y))), fmaxf(fabsf(f[k].z), fabsf(f[k].w)));
+    }
+    uint32_t be = (__float_as_uint(am) >> 23) & 0xffu;  // biased exponent of the unit's maximum (E_u = be - 127)
+    be = be < 24u ? 24u : be > 240u ? 240u : be;
+    const float sc = __uint_as_float((267u - be) << 23);  // 2^(13 - E_u)
+    qv16f lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float xs[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float q = __builtin_rintf(xs[e] * sc);
+            const float r1 = __builtin_rintf(q * 0.03125f), d0 = __builtin_fmaf(r1, -32.0f, q);
+            const float r2 = __builtin_rintf(r1 * 0.03125f), d1 = __builtin_fmaf(r2, -32.0f, r1);
+            const int ix = 4 * (k >> 1) + e;
+            if (k & 1) hi[0][ix] = d0, hi[1][ix] = d1, hi[2][ix] = r2;
+            else lo[0][ix] = d0, lo[1][ix] = d1, lo[2][ix] = r2;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const qv6u r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo[d], hi[d], 8.0f);  // (k-slot order: k_quant_rows explains)
+        uint2 *o = reinterpret_cast<uint2 *>(dst + d * 48);
+        o[0] = uint2{r[0], r[1]}, o[1] = uint2{r[2], r[3]}, o[2] = uint2{r[4], r[5]};
+    }
+    return be - 10u;
+}
+// where unit U (32 columns) of a token's row lives: digit records [token][blk = U / 8][g = (U / 2) % 4][digit][m = U % 2][24 bytes]
+__device__ __forceinline__ uint8_t *qb32_unit_ptr(uint8_t *planes, size_t token, int nblk, int U) {
+    return planes + (((size_t)token * nblk + (U >> 3)) * 4 + ((U >> 1) & 3)) * 144 + (U & 1) * 24;
+}
+
+// f32 rows -> QB32 of gamma * x (gamma nullable) + the row's (sum, sum of squares) as partial 0 of the consumer's LayerNorm statistics:
+// the QB32 chain's entry (the embedding rows), one workgroup per row -- the twin of k_rows_to_f16.
+__global__ __launch_bounds__(256) void k_rows_to_qb32(const float *__restrict__ x, const float *__restrict__ gamma, int m, int cols, uint8_t *__restrict__ planes,
+                                                      uint8_t *__restrict__ exps, float *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float qb_row[];
+    __shared__ double red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool live = row < m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < cols / 4; i += 256) {
+        float4 v = live ? *reinterpret_cast<const float4 *>(x + (size_t)row * cols + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        if (gamma) {
+            const float4 gm = *reinterpret_cast<const float4 *>(gamma + 4 * i);
+            v.x *= gm.x, v.y *= gm.y, v.z *= gm.z, v.w *= gm.w;
+        }
+        *reinterpret_cast<float4 *>(qb_row + ((i >> 3) * 9 + (i & 7)) * 4) = v;
+    }
+    s1 = qwave_sum_d(s1), s2 = qwave_sum_d(s2);
+    if (lane == 0) red[2 * wave] = s1, red[2 * wave + 1] = s2;
+    __syncthreads();
+    if (tid == 0 && stats) {
+        s1 = (red[0] + red[2]) + (red[4] + red[6]);
+        s2 = (red[1] + red[3]) + (red[5] + red[7]);
+        *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{(float)s1, (float)s2};
+    }
+    const int n_units = cols >> 5, nblk = cols >> 8;
+    for (int u = tid; u < n_units; u += 256) exps[(size_t)row * n_units + u] = (uint8_t)qb32_pack_unit(qb_row + u * 36, qb32_unit_ptr(planes, row, nblk, u));
+}
+
 // ---- the f16 chain's epilogues (k_gemm_f16a<.., EPI = 1>; NW = 8: the ring form of tools/probes/gemm_f16_ring.patch): NW waves of RT row tiles x TTW token tiles ------
-template <int RT, int TTW, int NW>
+// QB = true (TTW = 4 only): the outputs also leave as QB32 of gamma_out * y for the next fp6-form matmul (GemmArgs::qb_out): a token's NW RT / 2 units of
+// 32 output rows are staged in LDS half a token tile (32 tokens) at a time and packed one unit per work item (qb32_pack_unit).
+template <int RT, int TTW, int NW, bool QB = false>
 __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc)[RT][TTW], uint8_t *lds, int bx, int by, int rw, int c, int g, int tid) {
+    static_assert(!QB || TTW == 4, "the QB32 hand-over is staged in two halves of a 64-token tile");
     constexpr int WG_TOK = TTW * 16;
     // LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma;
     // mean / denom from the producer's per-slab partial sums of the exact f32 x, added up here in a fixed order (f64): deterministic
@@ -914,6 +1006,24 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                     *reinterpret_cast<gh4 *>(p.yh + off) = o;
                 }
             }
+            if (QB) {  // stage gamma_out * y: token (tt & 1) 16 + c of this half, columns 16 (rw RT + rt) + 4 g .. + 3 of the workgroup's NW RT 16
+                constexpr int NU = NW * RT / 2;
+                float *st = reinterpret_cast<float *>(lds + 8192);  // (behind the LayerNorm scratch of this function)
+                const int col = 16 * (rw * RT + rt) + 4 * g;
+                *reinterpret_cast<float4 *>(st + ((((tt & 1) * 16 + c) * NU + (col >> 5)) * 9) * 4 + (col & 31)) =
+                    float4{val[rt][0] * gout[rt][0], val[rt][1] * gout[rt][1], val[rt][2] * gout[rt][2], val[rt][3] * gout[rt][3]};
+            }
+        }
+        if (QB && (tt & 1)) {
+            constexpr int NU = NW * RT / 2;
+            const float *st = reinterpret_cast<const float *>(lds + 8192);
+            __syncthreads();
+            for (int i = tid; i < 32 * NU; i += NW * 64) {
+                const int tl = i / NU, u = i - tl * NU, U = bx * NU + u;
+                const size_t tok = (size_t)by * WG_TOK + (tt >> 1) * 32 + tl;  // (rows up to m_pad exist in every QB32 buffer)
+                p.qb_exps_out[tok * (size_t)(p.qb_nblk_out * 8) + U] = (uint8_t)qb32_pack_unit(st + (tl * NU + u) * 36, qb32_unit_ptr(p.qb_out, tok, p.qb_nblk_out, U));
+            }
+            __syncthreads();
         }
         if (p.stats_out) {  // this wave's 16 RT rows of the token: the consumer's LayerNorm adds the slabs up
             s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
@@ -931,7 +1041,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
 // 8 x 64 = 512 workgroups -- exactly one round of the 512 slots (two 4-wave workgroups per CU) instead of 640 in two rounds.
 template <int FMT, int TTW, int EPI = 0, int RT = 4>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_hi) {
-    static_assert(RT == 4 || EPI == 1, "the 5-tile wave exists for the chain's epilogue only");
+    static_assert(RT == 4 || EPI >= 1, "the 5-tile wave exists for the chain's epilogue only");  // EPI 2 = chain epilogue + QB32 hand-over
     constexpr int WG_TOK = TTW * 16, NB = WG_TOK * 32 / 256, ROWB = 512, kBuf = WG_TOK * ROWB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1105,7 +1215,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         return;
     }
-    f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, bx, by, rw, c, g, tid);
+    f16_chain_epilogue<RT, TTW, 4, EPI == 2>(p, acc, lds, bx, by, rw, c, g, tid);
 }
 
 // ================================================================================================================================
@@ -1152,11 +1262,13 @@ __global__ void k_retile_fp4(const uint8_t *__restrict__ tiles, uint8_t *__restr
 
 // RT = row tiles per wave: 4, or 5 (320-row workgroups: gemm_five_tiles; no silu * mul pairing with it).
 // RES = 1: A operands from the resident fp4 image (GemmArgs::tiles4) instead of expanding the 2-bit tiles in the loop.
-template <int TTW, int RT = 4, int RES = 0>
+// EPI = 1: QB32 activations in (per-unit exponent bytes beside the digit records: the B scale operand is per lane) and the f16 chain's epilogue out
+// (LayerNorm after the product from the producer's statistics partials, residual, silu * up as f16 rows, f32 rows).
+template <int TTW, int RT = 4, int RES = 0, int EPI = 0>
 __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {
     constexpr int T = 16 * TTW, UNITS = T * 36, NB = (UNITS + 255) / 256, kBuf = T * 576;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile bases below stay in SGPRs)
     const int c = lane & 15, g = lane >> 4, rw = wave;
     const int n_tiles = (p.rows + 15) >> 4;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -1175,23 +1287,27 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     }
     constexpr int NM = RES ? 2 : 1;            // 16-byte weight loads per row tile and K step
     constexpr size_t WSTEP = RES ? 2048 : 1024;  // bytes of one (tile, 256-block) in the layout read
-    const uint8_t *wptr[RT];
+    // Addresses are a wave-uniform base (SGPR pair) + a 32-bit lane offset (round 5: 64-bit per-lane pointers for 4-5 weight tiles, 9 staging
+    // units and 4 exponent rows took 40 registers and a v_mad_i64 per load; the QB32 form spilled on them)
+    const uint8_t *wptr[RT];  // uniform: this wave's row tiles
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         int t = bx * (4 * RT) + rw * RT + rt;
         t = t < n_tiles ? t : n_tiles - 1;
-        wptr[rt] = RES ? p.tiles4 + ((size_t)t * p.nblk * 128 + lane) * 16 : p.tiles + ((size_t)t * p.nblk * 64 + lane) * 16;
+        wptr[rt] = RES ? p.tiles4 + (size_t)t * p.nblk * 2048 : p.tiles + (size_t)t * p.nblk * 1024;
     }
+    const uint32_t woff = (uint32_t)lane * 16u;
     // this thread's 16-byte units of the activation tile: unit u of a token's 576 bytes = (g = u / 9, k = u % 9)
-    const size_t row_bytes = (size_t)p.nblk * 576;
-    const uint8_t *bsrc[NB];
+    const uint32_t row_bytes = (uint32_t)p.nblk * 576u;
+    const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)by * T * row_bytes;  // uniform
+    uint32_t bsrc[NB];
     int bdst[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         int idx = tid + 256 * i;
         idx = idx < UNITS ? idx : UNITS - 1;  // (surplus threads of the last round repeat its last unit: same bytes, same place)
         const int tok = idx / 36, u = idx % 36, gg = u / 9, k = u % 9;
-        bsrc[i] = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)(by * T + tok) * row_bytes + u * 16;
+        bsrc[i] = (uint32_t)tok * row_bytes + (uint32_t)u * 16u;
         bdst[i] = ((gg * T + tok) * 9 + k) * 16;
     }
     gv4f acc[RT][TTW];
@@ -1203,18 +1319,27 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + m * 1024);
+        for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + m * 1024 + woff);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i]);
+    for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + bsrc[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
     {
         const int n1 = p.nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 576);
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n1 * 576 + bsrc[i]);
     }
     __syncthreads();
     const int bread = (g * T + c) * 144;
+    // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) per token tile and K step, requested one step ahead
+    const uint32_t erow = (uint32_t)p.nblk * 8u, eoff = (uint32_t)c * erow + 2u * (uint32_t)g;
+    const uint8_t *ebase = EPI ? p.qb_exps + (size_t)by * T * erow : nullptr;  // uniform; token tile ct adds 16 erow, K step blk adds 8
+    uint32_t en[TTW], ec[TTW];
+#pragma unroll
+    for (int ct = 0; ct < TTW; ++ct) {
+        en[ct] = EPI ? *reinterpret_cast<const uint16_t *>(ebase + (size_t)ct * 16 * erow + eoff) : 0u;
+        ec[ct] = 0u;
+    }
 
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = lds + (blk & 1) * kBuf + bread;
@@ -1233,9 +1358,13 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * WSTEP + m * 1024);
+                for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * WSTEP + m * 1024 + woff);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n2 * 576);
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n2 * 576 + bsrc[i]);
+            if (EPI) {
+#pragma unroll
+                for (int ct = 0; ct < TTW; ++ct) ec[ct] = en[ct], en[ct] = *reinterpret_cast<const uint16_t *>(ebase + (size_t)ct * 16 * erow + (size_t)n1 * 8 + eoff);
+            }
         }
         // B operands one group (token tile, digit) ahead of their MFMAs: hipcc otherwise waits for every group's reads right after
         // issuing them; group 0 is requested ahead of the code expansion
@@ -1279,17 +1408,23 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
             const v4i r0 = rr[grp & 1][0], r1 = rr[grp & 1][1], r2 = rr[grp & 1][2];
             const gv8i b0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1);
             const gv8i b1 = __builtin_shufflevector(r1, r2, 2, 3, 4, 5, 6, 7, -1, -1);
+            // B scale byte (byte 0 of the operand): the digit's weight 2^(3 + 5 d) -- times the unit's own 2^(E_u - 13) on QB32 rows (s_u + 5 d)
+            const int sb0 = EPI ? (int)(ec[ct] & 0xffu) + 5 * d : 130 + 5 * d, sb1 = EPI ? (int)(ec[ct] >> 8) + 5 * d : 130 + 5 * d;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[0][rt], a[0][rt], 0, 1, 2, 3, -1, -1, -1, -1), b0, acc[rt][ct], 4, 2, 0,
-                                                                               127, 0, 130 + 5 * d);
+                                                                               127, 0, sb0);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[1][rt], a[1][rt], 0, 1, 2, 3, -1, -1, -1, -1), b1, acc[rt][ct], 4, 2, 0,
-                                                                               127, 0, 130 + 5 * d);
+                                                                               127, 0, sb1);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    }
+    if (EPI) {
+        f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, bx, by, rw, c, g, tid);
+        return;
     }
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
@@ -1656,6 +1791,13 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     void (*fk)(GemmArgs, uint32_t) = rt5    ? (fmt1 ? k_gemm_f16a<1, 4, 1, 5> : k_gemm_f16a<0, 4, 1, 5>)
                                      : fmt1 ? (ttw == 4 ? k_gemm_f16a<1, 4, 1> : ttw == 2 ? k_gemm_f16a<1, 2, 1> : k_gemm_f16a<1, 1, 1>)
                                             : (ttw == 4 ? k_gemm_f16a<0, 4, 1> : ttw == 2 ? k_gemm_f16a<0, 2, 1> : k_gemm_f16a<0, 1, 1>);
+    if (io.qb_out) {  // the outputs also leave as QB32 rows (the next fp6-form matmul's input): 64-token tiles only, no silu pairing, K' = rows % 256 == 0
+        if (ttw != 4 || io.silu_mul || w.rows % 256 != 0) return hipErrorInvalidValue;
+        fk = rt5 ? (fmt1 ? k_gemm_f16a<1, 4, 2, 5> : k_gemm_f16a<0, 4, 2, 5>) : (fmt1 ? k_gemm_f16a<1, 4, 2> : k_gemm_f16a<0, 4, 2>);
+        a.qb_nblk_out = (int)(w.rows / 256);
+        a.qb_out = static_cast<uint8_t *>(io.qb_out);
+        a.qb_exps_out = a.qb_out + m_pad * (size_t)a.qb_nblk_out * 576;
+    }
     {
         static std::mutex f_mu;
         static std::unordered_set<const void *> f_raised;
@@ -1670,6 +1812,73 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     const size_t lds = (size_t)2 * ttw * 16 * 512;  // (the epilogue's 5 KiB of statistics scratch fit the smallest tile pair: 16 KiB)
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, w.cols, fmt1);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
+    return hipGetLastError();
+}
+
+size_t qb32_bytes(size_t m, size_t cols) {
+    const size_t m_pad = div_ceil(m, 64) * 64, nblk = div_ceil(cols, 256);
+    return m_pad * nblk * 576 + m_pad * nblk * 8 + 256;
+}
+
+hipError_t launch_rows_to_qb32(const float *x, const float *gamma, size_t m, size_t cols, void *qb, float *stats, hipStream_t stream) {
+    if (cols % 256 != 0 || m == 0 || cols > 8192) return hipErrorInvalidValue;
+    const size_t m_pad = div_ceil(m, 64) * 64, nblk = cols / 256;
+    uint8_t *planes = static_cast<uint8_t *>(qb);
+    hipLaunchKernelGGL(k_rows_to_qb32, dim3((unsigned)m_pad), dim3(256), (cols / 32) * 144, stream, x, gamma, (int)m, (int)cols, planes, planes + m_pad * nblk * 576, stats);
+    return hipGetLastError();
+}
+
+bool gemm_qb32_supported(const Weights &w) { return gemm_fp6_supported(w) && w.rows % 256 == 0 && w.cols % 256 == 0; }
+
+hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream) {
+    if (!gemm_qb32_supported(w) || m == 0 || !io.xh || io.qb_out) return hipErrorInvalidValue;
+    if (io.stats_in && !(w.ln_g && io.n_stats > 0)) return hipErrorInvalidValue;
+    if (io.silu_mul && (!w.paired || io.residual)) return hipErrorInvalidValue;
+    const size_t m_pad = div_ceil(m, 64) * 64, nblk = w.cols / 256;
+    GemmArgs a;
+    a.tiles = w.tiles;
+    a.tiles4 = gemm_fp4_resident_enabled() ? w.tiles4 : nullptr;
+    a.stiles_h = nullptr;
+    a.rows = (int)w.rows;
+    a.cols = (int)w.cols;
+    a.nblk = (int)nblk;
+    a.lut = w.lut;
+    a.planes = static_cast<const int8_t *>(io.xh);
+    a.qb_exps = static_cast<const uint8_t *>(io.xh) + m_pad * nblk * 576;
+    a.inv_scale = nullptr;
+    a.y = io.y;
+    a.m = (int)m;
+    a.residual = io.residual;
+    a.wscale = nullptr;
+    a.silu_mul = io.silu_mul ? 1 : 0;
+    a.stats_in = io.stats_in;
+    a.n_stats = io.n_stats;
+    a.stats_stride = (int)m_pad;
+    a.ln_eps = io.ln_eps;
+    a.ln_g = w.ln_g;
+    a.yh = static_cast<_Float16 *>(io.yh);
+    a.gamma_out = io.gamma_out;
+    a.stats_out = io.stats_out;
+    size_t gx0 = w.rows / 256;
+    const int ttw = gemm_token_tiles(gx0, m_pad, false);
+    const bool rt5 = ttw == 4 && !io.silu_mul && gemm_five_tiles(w.rows, m_pad);
+    if (rt5) gx0 = w.rows / 320;
+    const bool res = a.tiles4 != nullptr;
+    void (*fk)(GemmArgs, uint32_t) = res ? (rt5 ? k_gemm_fp6<4, 5, 1, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 1, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 1, 1> : k_gemm_fp6<1, 4, 1, 1>)
+                                         : (rt5 ? k_gemm_fp6<4, 5, 0, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 0, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 0, 1> : k_gemm_fp6<1, 4, 0, 1>);
+    {
+        static std::mutex f_mu;
+        static std::unordered_set<const void *> f_raised;
+        std::lock_guard<std::mutex> lk(f_mu);
+        if (!f_raised.count((const void *)fk)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            f_raised.insert((const void *)fk);
+        }
+    }
+    g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 8, rt5 ? 80 : 64, res ? 1 : 0};  // scale_mode 8: the fp6 form on QB32 rows
+    a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, a, lut_fp4(w.lut));
     return hipGetLastError();
 }
 

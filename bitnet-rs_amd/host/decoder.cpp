@@ -176,7 +176,7 @@ Decoder::~Decoder() {
                     (void *)history_, (void *)token_})
         if (p) hipFree(p);
     for (void *p : {(void *)pf_x_, (void *)pf_qkv_, (void *)pf_att_, (void *)pf_h_, pf_gemm_ws_, pf_attn_ws_, sp_kv_send_, sp_kv_all_,
-                    (void *)sp_block_pos_, (void *)sp_tokens_, pf_xh_, pf_atth_, pf_hh_, (void *)pf_stats_})
+                    (void *)sp_block_pos_, (void *)sp_tokens_, pf_xh_, pf_atth_, pf_hh_, (void *)pf_stats_, pf_qb_})
         if (p) hipFree(p);
     for (void *e : sp_tev_)
         if (e) hipEventDestroy((hipEvent_t)e);
@@ -839,6 +839,62 @@ int Decoder::prefill_chain_layers(size_t N) {
     return 0;
 }
 
+// The QK256 prompt forward with NO row quantiser launch (round 5): q|k|v and gate|up run the fp6 x fp4 form on QB32 rows -- block-scaled 15-bit
+// fixed point, one exponent per 32 columns of a token -- that the kernel PRODUCING the residual stream wrote: the o- / down-projection (f16 matrix
+// cores, 320-row workgroups: the hybrid forward's launches) leaves x (f32), QB32(gamma_next * x) and the LayerNorm statistics partials in its
+// epilogue (BITNET_HIP_FUSE_YH_QB32); LayerNorm is applied after the product (as on the f16 chain and in the decode step).  Only where the hybrid
+// forward applies (long prompts: the producers then run 64-token tiles) and every q|k|v / gate|up matrix takes the form; BITNET_HOST_PREFILL_QB32=0
+// restores the quantiser launches.
+bool Decoder::qb32_applies(int digits, size_t n_rows) {
+    if (prefill_qb32_ < 0) {
+        const char *e = getenv("BITNET_HOST_PREFILL_QB32");
+        prefill_qb32_ = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+    }
+    if (!prefill_qb32_ || digits != 2 || !handover16_applies(digits) || !hybrid_applies(n_rows) || !fp6_flag(digits)) return false;
+    for (const auto &L : layers_)
+        for (bitnet_hip_weights_t h : {L.qkv, L.gateup})
+            if (!h || bitnet_hip_matmul_qb32_supported(h) != 1) return false;
+    return true;
+}
+
+int Decoder::prefill_qb32_layers(size_t N) {
+    const size_t H = c_.hidden, nst = H / 64;
+    hipStream_t s = (hipStream_t)stream_;
+    {
+        const int rc = ensure_chain_buffers(N);
+        if (rc) return rc;
+    }
+    const size_t NP = (N + 63) / 64 * 64;
+    if ((int)NP > pf_qb_cap_) {
+        if (pf_qb_) (void)hipFree(pf_qb_);
+        pf_qb_ = nullptr;
+        pf_qb_cap_ = 0;
+        HCHK(hipMalloc(&pf_qb_, bitnet_hip_qb32_bytes(NP, H)));
+        HCHK(hipMemsetAsync(pf_qb_, 0, bitnet_hip_qb32_bytes(NP, H), s));
+        pf_qb_cap_ = (int)NP;
+    }
+    BCHK(bitnet_hip_rows_to_qb32_dev(pf_x_, layers_[0].attn_norm, N, H, pf_qb_, pf_stats_, s));
+    size_t n_stats = 1;
+    const int aflags = (kv_f16_ ? BITNET_HIP_ATTN_CACHE_F16 : 0) | BITNET_HIP_ATTN_OUT_F16;
+    for (size_t l = 0; l < layers_.size(); ++l) {
+        auto &L = layers_[l];
+        BCHK(bitnet_hip_matmul_qb32_dev(L.qkv, pf_qb_, N, pf_stats_, n_stats, L.attn_norm, c_.eps, pf_qkv_, nullptr, 0, nullptr, nullptr, nullptr, s));
+        BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads,
+                                                    (size_t)c_.head_dim, (size_t)c_.max_pos, N, pf_attn_ws_, pf_attn_ws_bytes_, pf_atth_, aflags, s));
+        BCHK(bitnet_hip_matmul_f16_dev(L.o, pf_atth_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, BITNET_HIP_FUSE_YH_QB32, pf_qb_, L.ffn_norm, pf_stats_, s));
+        n_stats = nst;
+        BCHK(bitnet_hip_matmul_qb32_dev(L.gateup, pf_qb_, N, pf_stats_, n_stats, L.ffn_norm, c_.eps, nullptr, nullptr, BITNET_HIP_FUSE_SILU_MUL, pf_hh_, nullptr,
+                                        nullptr, s));
+        const bool last = l + 1 == layers_.size();
+        if (last)
+            BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, 0, nullptr, nullptr, nullptr, s));
+        else
+            BCHK(bitnet_hip_matmul_f16_dev(L.down, pf_hh_, N, nullptr, 0, nullptr, 0.f, pf_x_, pf_x_, BITNET_HIP_FUSE_YH_QB32, pf_qb_, layers_[l + 1].attn_norm,
+                                           pf_stats_, s));
+    }
+    return 0;
+}
+
 int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     if (!embed_) {
         err_ = "model globals not set";
@@ -890,7 +946,12 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         const int rc = prefill_chain_layers(N);
         if (rc) return rc;
     }
-    const bool h16 = !chain && handover16_applies(digits);
+    const bool qb = !chain && qb32_applies(digits, N);
+    if (qb) {
+        const int rc = prefill_qb32_layers(N);
+        if (rc) return rc;
+    }
+    const bool h16 = !chain && !qb && handover16_applies(digits);
     if (h16) {
         const int rc = ensure_chain_buffers(N);
         if (rc) return rc;
@@ -899,11 +960,11 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     // matrix cores as they stand (k_gemm_f16a, 320-row workgroups: one round of the chip at 4096 tokens) -- no quantiser launch, no second
     // rounding of values that were rounded to f16 already; q|k|v and gate|up keep the faster int8 digit planes behind their LayerNorm.
     const bool hybrid = h16 && hybrid_applies(N);
-    const int f6 = chain ? 0 : fp6_flag(digits);
+    const int f6 = (chain || qb) ? 0 : fp6_flag(digits);
     static const int f6od_env = getenv("BITNET_HOST_PREFILL_FP6_OD") ? atoi(getenv("BITNET_HOST_PREFILL_FP6_OD")) : 0;  // experiment: o / down on the fp6 form too (non-hybrid)
     const int f6od = f6od_env ? f6 : 0;
     for (auto &L : layers_) {
-        if (chain) break;
+        if (chain || qb) break;
         BCHK(bitnet_hip_matmul_fused_dev(L.qkv, pf_x_, pf_qkv_, N, L.attn_norm, c_.eps, nullptr, f6, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
         if (h16) {
             BCHK(bitnet_hip_attention_prefill_flags_dev(pf_qkv_, rope_sin_, rope_cos_, L.kcache, L.vcache, (size_t)c_.n_heads, (size_t)c_.n_kv_heads, (size_t)c_.head_dim,

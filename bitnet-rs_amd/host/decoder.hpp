@@ -120,6 +120,8 @@ class Decoder {
     int fp6_flag(int digits);  // BITNET_HIP_FUSE_FP6_DIGITS for the q|k|v and gate|up launches of the digit-plane prompt forward, or 0
     int ensure_chain_buffers(size_t N);
     int prefill_chain_layers(size_t N);
+    bool qb32_applies(int digits, size_t n_rows);  // the QK256 prompt forward on QB32 rows (no row quantiser launch): long prompts, digits = 2
+    int prefill_qb32_layers(size_t N);
     void set_phase_timing(bool on) { sp_timing_ = on; }
     void phase_times(float out[4]) const {
         for (int i = 0; i < 4; ++i) out[i] = sp_phase_us_[i];
@@ -213,6 +215,9 @@ class Decoder {
     int pfc_cap_ = 0;
     void *pf_xh_ = nullptr, *pf_atth_ = nullptr, *pf_hh_ = nullptr;
     float *pf_stats_ = nullptr;
+    void *pf_qb_ = nullptr;   // QB32 rows of gamma * x (the input of q|k|v and of gate|up), bitnet_hip_qb32_bytes(pfc_cap_, hidden)
+    int pf_qb_cap_ = 0;
+    int prefill_qb32_ = -1;   // BITNET_HOST_PREFILL_QB32: -1 automatic (on where it applies), 0 off
     int prefill_fp6_ = -1;    // BITNET_HOST_PREFILL_FP6: -1 not yet decided, 0 int8 digit planes, 1 the fp6 x fp4 form on resident fp4 images (fp6_flag)
     int prefill_chain_ = -1;  // BITNET_HOST_PREFILL_CHAIN: -1 automatic (the block-scaled format, whose matmul runs on f16 activations anyway), 0 off, 1 on
     size_t pf_gemm_ws_bytes_ = 0, pf_attn_ws_bytes_ = 0;

@@ -282,6 +282,26 @@ int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t w, const void *xh_dev, size_t
                               const float *ln_gamma_dev, float ln_eps, float *y_dev, const float *residual_dev, int flags, void *yh_dev,
                               const float *gamma_out_dev, float *stats_out_dev, void *stream);
 
+/* QB32 ACTIVATIONS (round 5): the producer-quantised input of the fp6 x fp4 prompt matmul -- what QAct is to the decode GEMV.  The digit forms'
+ * row quantiser needs the row maximum, which no producing workgroup has, so it stayed a launch of its own (two per layer, 6 % of the QK256
+ * prompt).  The block-scaled MFMA takes one E8M0 scale per 32 K-slots of a token, so a QB32 row scales LOCALLY: per 32-column unit, E = exponent
+ * of the unit's largest |v|, q = rint(v 2^(13 - E)) as three balanced base-32 fp6 digits (the 15-bit integer class of the 2-digit planes), one
+ * exponent byte per unit.  Buffer: digit records [m_pad][cols / 256][576] then [m_pad][cols / 32] bytes, m_pad = m rounded up to 64
+ * (bitnet_hip_qb32_bytes).  LayerNorm is applied after the product from the producer's statistics partials, as on the f16 chain.
+ *   bitnet_hip_rows_to_qb32_dev: f32 rows -> QB32 of gamma * x (gamma nullable) + stats partial 0: the chain's entry (the embedding rows).
+ *   bitnet_hip_matmul_f16_dev(..., flags | BITNET_HIP_FUSE_YH_QB32, yh_dev = a QB32 buffer of [m][rows], gamma_out, stats_out): the o- / down-
+ *     projection's epilogue leaves gamma_out * y as QB32 rows (64-token tiles: m_pad / 64 * rows / 256 >= 256 workgroups; no FUSE_SILU_MUL).
+ *   bitnet_hip_matmul_qb32_dev: bitnet_hip_matmul_f16_dev's arguments with a QB32 buffer as the input: y / residual / FUSE_SILU_MUL / yh (f16
+ *     rows) / gamma_out / stats_out as there; matrices: unscaled, code map in -2..2, rows % 256 == 0, cols % 256 == 0 (reads the resident fp4
+ *     image, building it on first use).  Replaces the reference's per-row loop T:683-691 / T:924 over many activation rows. */
+#define BITNET_HIP_FUSE_YH_QB32 64
+size_t bitnet_hip_qb32_bytes(size_t m, size_t cols);
+int bitnet_hip_rows_to_qb32_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *qb_dev, float *stats_dev, void *stream);
+int bitnet_hip_matmul_qb32_supported(bitnet_hip_weights_t w);
+int bitnet_hip_matmul_qb32_dev(bitnet_hip_weights_t w, const void *qb_dev, size_t m, const float *stats_in_dev, size_t n_stats,
+                               const float *ln_gamma_dev, float ln_eps, float *y_dev, const float *residual_dev, int flags, void *yh_dev,
+                               const float *gamma_out_dev, float *stats_out_dev, void *stream);
+
 /* Several uploaded matrices with the same cols / code map / block size as ONE
  * launch: rows concatenated (q|k|v share their input: T:288-290).  interleave16 != 0
  * (exactly two matrices of equal rows % 16 == 0) alternates 16-row tiles a0,b0,a1,b1..
