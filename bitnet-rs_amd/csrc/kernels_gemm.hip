@@ -61,12 +61,11 @@ struct GemmArgs {
     float *stats_out = nullptr;        // (sum, sum of squares) of the f32 outputs per (64-row slab, token): [rows / 64][stats_stride] float2
     unsigned long long *stamps = nullptr;  // diagnostic build (BH_STAMPS): per wave 8 x u64 of phase cycles, tools/stamp_f16a.py
     // ---- QB32 activations (round 5; k_gemm_fp6<.., EPI = 1> consumes, f16_chain_epilogue<.., QB = true> / k_rows_to_qb32 produce): `planes` = the digit
-    // records [m_pad][nblk][576] (the fp6 form's layout), one E8M0-ready exponent byte per (token, 32-column unit) beside them ----------------------------
-    const uint8_t *qb_exps = nullptr;  // [m_pad][nblk * 8]
-    uint8_t *qb_out = nullptr;         // producer: digit records of the OUTPUT rows [m_pad][qb_nblk_out][576] (gamma_out * y, the next matmul's K = rows)
-    uint8_t *qb_exps_out = nullptr;    // [m_pad][qb_nblk_out * 8]
+    // records [m_pad][nblk][592]: 576 bytes of digits (the fp6 form's layout) + the block's eight E8M0-ready exponent bytes (one per 32-column unit) + 8 pad ----
+    uint8_t *qb_out = nullptr;         // producer: records of the OUTPUT rows [m_pad][qb_nblk_out][592] (gamma_out * y, the next matmul's K = rows)
     int qb_nblk_out = 0;
     const uint8_t *tiles4 = nullptr;  // k_gemm_fp6<.., RES = 1>: the resident fp4 image [n_tiles][nblk][m 2][64][16] (k_retile_fp4)
+    int ablate = 0;  // developer timing only (BITNET_HIP_QB_ABLATE: wrong results): 1 no exponent loads, 2 no LayerNorm statistics, 4 no hand-over pack
     int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
 
@@ -872,15 +871,21 @@ __device__ __forceinline__ uint32_t qb32_pack_unit(const float *src, uint8_t *ds
     }
     return be - 10u;
 }
-// where unit U (32 columns) of a token's row lives: digit records [token][blk = U / 8][g = (U / 2) % 4][digit][m = U % 2][24 bytes]
+// where unit U (32 columns) of a token's row lives: records [token][blk = U / 8] of kQbRec = 592 bytes = digits [g = (U / 2) % 4][digit][m = U % 2][24 bytes]
+// (576 bytes, the 36 sixteen-byte units the matmul stages per token and K step) + exponent byte U % 8 at 576 (unit 36: staged with them -- as a
+// separate array the bytes were four 2-byte gathers per lane and K step, which cost the vector-memory path 0.5 us per K step: 40 us per layer)
+constexpr int kQbRec = 592;
 __device__ __forceinline__ uint8_t *qb32_unit_ptr(uint8_t *planes, size_t token, int nblk, int U) {
-    return planes + (((size_t)token * nblk + (U >> 3)) * 4 + ((U >> 1) & 3)) * 144 + (U & 1) * 24;
+    return planes + ((size_t)token * nblk + (U >> 3)) * kQbRec + ((U >> 1) & 3) * 144 + (U & 1) * 24;
+}
+__device__ __forceinline__ uint8_t *qb32_exp_ptr(uint8_t *planes, size_t token, int nblk, int U) {
+    return planes + ((size_t)token * nblk + (U >> 3)) * kQbRec + 576 + (U & 7);
 }
 
 // f32 rows -> QB32 of gamma * x (gamma nullable) + the row's (sum, sum of squares) as partial 0 of the consumer's LayerNorm statistics:
 // the QB32 chain's entry (the embedding rows), one workgroup per row -- the twin of k_rows_to_f16.
 __global__ __launch_bounds__(256) void k_rows_to_qb32(const float *__restrict__ x, const float *__restrict__ gamma, int m, int cols, uint8_t *__restrict__ planes,
-                                                      uint8_t *__restrict__ exps, float *__restrict__ stats) {
+                                                      float *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float qb_row[];
     __shared__ double red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -905,27 +910,51 @@ __global__ __launch_bounds__(256) void k_rows_to_qb32(const float *__restrict__ 
         *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{(float)s1, (float)s2};
     }
     const int n_units = cols >> 5, nblk = cols >> 8;
-    for (int u = tid; u < n_units; u += 256) exps[(size_t)row * n_units + u] = (uint8_t)qb32_pack_unit(qb_row + u * 36, qb32_unit_ptr(planes, row, nblk, u));
+    for (int u = tid; u < n_units; u += 256) *qb32_exp_ptr(planes, row, nblk, u) = (uint8_t)qb32_pack_unit(qb_row + u * 36, qb32_unit_ptr(planes, row, nblk, u));
 }
 
 // ---- the f16 chain's epilogues (k_gemm_f16a<.., EPI = 1>; NW = 8: the ring form of tools/probes/gemm_f16_ring.patch): NW waves of RT row tiles x TTW token tiles ------
-// QB = true (TTW = 4 only): the outputs also leave as QB32 of gamma_out * y for the next fp6-form matmul (GemmArgs::qb_out): a token's NW RT / 2 units of
-// 32 output rows are staged in LDS half a token tile (32 tokens) at a time and packed one unit per work item (qb32_pack_unit).
-template <int RT, int TTW, int NW, bool QB = false>
-__device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc)[RT][TTW], uint8_t *lds, int bx, int by, int rw, int c, int g, int tid) {
-    static_assert(!QB || TTW == 4, "the QB32 hand-over is staged in two halves of a 64-token tile");
-    constexpr int WG_TOK = TTW * 16;
-    // LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma;
-    // mean / denom from the producer's per-slab partial sums of the exact f32 x, added up here in a fixed order (f64): deterministic
-    float2 *mu_rs = reinterpret_cast<float2 *>(lds);  // (the K loop's last barrier is behind every wave: the tile buffers are free)
-    if (p.stats_in) {
-        constexpr int NG = NW * 64 / WG_TOK;
-        double *red = reinterpret_cast<double *>(lds + 1024);
-        const int tk = tid % WG_TOK, pg = tid / WG_TOK;
+// LayerNorm after the product (T:67-100 applied to the INPUT): W . LN(x) = (W . (gamma * x) - mean g) / denom, g_r = W[r, :] . gamma; mean / denom of
+// the workgroup's WG_TOK tokens from the producer's per-slab partial sums of the exact f32 x, added up in a fixed order (f64): deterministic.
+// Runs in the PROLOGUE of the consuming kernel (round 5), while the first tiles' loads are in flight: at the start of the epilogue it was 10
+// dependent L2 round trips (later one batch of 10 loads) plus two barriers that no MFMA of the workgroup overlapped -- 7 us of a 40 us gate|up
+// workgroup.  `red` = 16 * NW * 64 bytes of scratch that nobody else touches before the next barrier; mu_rs = WG_TOK float2 that live to the epilogue.
+// Two halves: the loads of the first ten partials per thread are ISSUED before the kernel's first tile loads (their round trip -- the partials were
+// written by the previous kernel on other XCDs -- then runs beside the tile's), the sums are FINISHED behind the tile's staging.
+template <int WG_TOK, int NW>
+struct ChainLnStats {
+    static constexpr int NG = NW * 64 / WG_TOK;
+    float2 v[10];
+    const float *sp;
+    int pg;
+    __device__ __forceinline__ void issue(const GemmArgs &p, int by, int tid) {
+        const int tk = tid % WG_TOK;
+        pg = tid / WG_TOK;
+        sp = p.stats_in + 2 * ((size_t)by * WG_TOK + tk);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            // UNCONDITIONAL loads (index clamped, value selected): behind a per-load condition hipcc put `s_waitcnt vmcnt(0)` + the f64
+            // conversion inside every branch -- ten serial round trips, 4.5 us per workgroup, 1.5 ms of a 4096-token prompt
+            const int i = pg + k * NG, ic = i < p.n_stats ? i : p.n_stats - 1;
+            v[k] = *reinterpret_cast<const float2 *>(sp + 2 * (size_t)ic * p.stats_stride);  // (finish() zeroes the clamped ones: no use of the value here,
+        }                                                                                  //  so no wait ahead of the tile loads that follow)
+    }
+    __device__ __forceinline__ void finish(const GemmArgs &p, double *red, float2 *mu_rs, int tid) {
         double s1 = 0.0, s2 = 0.0;
-        for (int i = pg; i < p.n_stats; i += NG) {
-            const float2 v = *reinterpret_cast<const float2 *>(p.stats_in + 2 * ((size_t)i * p.stats_stride + by * WG_TOK + tk));
-            s1 += (double)v.x, s2 += (double)v.y;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const bool in = pg + k * NG < p.n_stats;
+            s1 += (double)(in ? v[k].x : 0.0f), s2 += (double)(in ? v[k].y : 0.0f);  // (+ 0.0 past the end: the sum is unchanged)
+        }
+        for (int i0 = pg + 10 * NG; i0 < p.n_stats; i0 += 10 * NG) {  // more than 10 NG partials (K > 2560): further batches, same fixed order
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const int i = i0 + k * NG, ic = i < p.n_stats ? i : p.n_stats - 1;
+                const float2 t = *reinterpret_cast<const float2 *>(sp + 2 * (size_t)ic * p.stats_stride);
+                v[k] = float2{i < p.n_stats ? t.x : 0.0f, i < p.n_stats ? t.y : 0.0f};
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) s1 += (double)v[k].x, s2 += (double)v[k].y;
         }
         red[2 * tid] = s1, red[2 * tid + 1] = s2;
         __syncthreads();
@@ -937,8 +966,15 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
             const float denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
             mu_rs[tid] = float2{(float)mean_d, 1.0f / denom};
         }
-        __syncthreads();
     }
+};
+
+// QB = true (TTW = 4 only): the outputs also leave as QB32 of gamma_out * y for the next fp6-form matmul (GemmArgs::qb_out): a token's NW RT / 2 units of
+// 32 output rows are staged in LDS half a token tile (32 tokens) at a time and packed one unit per work item (qb32_pack_unit).
+template <int RT, int TTW, int NW, bool QB = false>
+__device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc)[RT][TTW], uint8_t *lds, const float2 *mu_rs, int bx, int by, int rw, int c, int g, int tid) {
+    static_assert(!QB || TTW == 4, "the QB32 hand-over is staged in two halves of a 64-token tile");
+    constexpr int WG_TOK = TTW * 16;
     const int tile0 = bx * (NW * RT) + rw * RT;
     float lng[RT][4], gout[RT][4];
 #pragma unroll
@@ -1014,14 +1050,14 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                     float4{val[rt][0] * gout[rt][0], val[rt][1] * gout[rt][1], val[rt][2] * gout[rt][2], val[rt][3] * gout[rt][3]};
             }
         }
-        if (QB && (tt & 1)) {
+        if (QB && (tt & 1) && !(p.ablate & 4)) {
             constexpr int NU = NW * RT / 2;
             const float *st = reinterpret_cast<const float *>(lds + 8192);
             __syncthreads();
             for (int i = tid; i < 32 * NU; i += NW * 64) {
                 const int tl = i / NU, u = i - tl * NU, U = bx * NU + u;
                 const size_t tok = (size_t)by * WG_TOK + (tt >> 1) * 32 + tl;  // (rows up to m_pad exist in every QB32 buffer)
-                p.qb_exps_out[tok * (size_t)(p.qb_nblk_out * 8) + U] = (uint8_t)qb32_pack_unit(st + (tl * NU + u) * 36, qb32_unit_ptr(p.qb_out, tok, p.qb_nblk_out, U));
+                *qb32_exp_ptr(p.qb_out, tok, p.qb_nblk_out, U) = (uint8_t)qb32_pack_unit(st + (tl * NU + u) * 36, qb32_unit_ptr(p.qb_out, tok, p.qb_nblk_out, U));
             }
             __syncthreads();
         }
@@ -1088,6 +1124,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
+    ChainLnStats<WG_TOK, 4> lnst;
+    const bool ln_in = EPI && p.stats_in;
+    if (ln_in) lnst.issue(p, by, tid);
     gv4u wn[RT], bn[NB];
     uint32_t sn[RT];
 #pragma unroll
@@ -1105,6 +1144,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 #pragma unroll
         for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 512);
     }
+    // the input LayerNorm's (mean, 1 / denom) per token, behind the tile buffers; the reduction's scratch is tile buffer 1 (free until the barrier below)
+    float2 *mu_rs = reinterpret_cast<float2 *>(lds + 2 * kBuf);
+    if (ln_in) lnst.finish(p, reinterpret_cast<double *>(lds + kBuf), mu_rs, tid);
     __syncthreads();
 
 #ifdef BH_STAMPS
@@ -1215,7 +1257,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         }
         return;
     }
-    f16_chain_epilogue<RT, TTW, 4, EPI == 2>(p, acc, lds, bx, by, rw, c, g, tid);
+    f16_chain_epilogue<RT, TTW, 4, EPI == 2>(p, acc, lds, mu_rs, bx, by, rw, c, g, tid);
 }
 
 // ================================================================================================================================
@@ -1266,7 +1308,8 @@ __global__ void k_retile_fp4(const uint8_t *__restrict__ tiles, uint8_t *__restr
 // (LayerNorm after the product from the producer's statistics partials, residual, silu * up as f16 rows, f32 rows).
 template <int TTW, int RT = 4, int RES = 0, int EPI = 0>
 __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {
-    constexpr int T = 16 * TTW, UNITS = T * 36, NB = (UNITS + 255) / 256, kBuf = T * 576;
+    // EPI: QB32 records (kQbRec = 592 bytes): unit 36 of a token's record holds the block's eight exponent bytes and is staged behind the digit tile
+    constexpr int T = 16 * TTW, REC = EPI ? kQbRec : 576, UPT = REC / 16, UNITS = T * UPT, NB = (UNITS + 255) / 256, kDig = T * 576, kBuf = kDig + (EPI ? T * 16 : 0);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile bases below stay in SGPRs)
     const int c = lane & 15, g = lane >> 4, rw = wave;
@@ -1298,7 +1341,7 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     }
     const uint32_t woff = (uint32_t)lane * 16u;
     // this thread's 16-byte units of the activation tile: unit u of a token's 576 bytes = (g = u / 9, k = u % 9)
-    const uint32_t row_bytes = (uint32_t)p.nblk * 576u;
+    const uint32_t row_bytes = (uint32_t)p.nblk * (uint32_t)REC;
     const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)by * T * row_bytes;  // uniform
     uint32_t bsrc[NB];
     int bdst[NB];
@@ -1306,10 +1349,13 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     for (int i = 0; i < NB; ++i) {
         int idx = tid + 256 * i;
         idx = idx < UNITS ? idx : UNITS - 1;  // (surplus threads of the last round repeat its last unit: same bytes, same place)
-        const int tok = idx / 36, u = idx % 36, gg = u / 9, k = u % 9;
+        const int tok = idx / UPT, u = idx % UPT, gg = u / 9, k = u % 9;
         bsrc[i] = (uint32_t)tok * row_bytes + (uint32_t)u * 16u;
-        bdst[i] = ((gg * T + tok) * 9 + k) * 16;
+        bdst[i] = u < 36 ? ((gg * T + tok) * 9 + k) * 16 : kDig + tok * 16;
     }
+    ChainLnStats<T, 4> lnst;
+    const bool ln_in = EPI && p.stats_in && !(p.ablate & 2);
+    if (ln_in) lnst.issue(p, by, tid);
     gv4f acc[RT][TTW];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -1327,19 +1373,18 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     {
         const int n1 = p.nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n1 * 576 + bsrc[i]);
+        for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n1 * REC + bsrc[i]);
     }
+    // (EPI) the input LayerNorm's (mean, 1 / denom) per token, behind the tile buffers; scratch = tile buffer 1, free until the barrier below
+    float2 *mu_rs = reinterpret_cast<float2 *>(lds + 2 * kBuf);
+    if (ln_in) lnst.finish(p, reinterpret_cast<double *>(lds + kBuf), mu_rs, tid);
     __syncthreads();
     const int bread = (g * T + c) * 144;
     // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) per token tile and K step, requested one step ahead
-    const uint32_t erow = (uint32_t)p.nblk * 8u, eoff = (uint32_t)c * erow + 2u * (uint32_t)g;
-    const uint8_t *ebase = EPI ? p.qb_exps + (size_t)by * T * erow : nullptr;  // uniform; token tile ct adds 16 erow, K step blk adds 8
-    uint32_t en[TTW], ec[TTW];
+    const int eread = kDig + c * 16 + 2 * g;  // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) of token tile ct: + 256 ct
+    uint32_t ec[TTW];
 #pragma unroll
-    for (int ct = 0; ct < TTW; ++ct) {
-        en[ct] = EPI ? *reinterpret_cast<const uint16_t *>(ebase + (size_t)ct * 16 * erow + eoff) : 0u;
-        ec[ct] = 0u;
-    }
+    for (int ct = 0; ct < TTW; ++ct) ec[ct] = 0u;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = lds + (blk & 1) * kBuf + bread;
@@ -1360,11 +1405,11 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
 #pragma unroll
                 for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * WSTEP + m * 1024 + woff);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n2 * 576 + bsrc[i]);
-            if (EPI) {
+            for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n2 * REC + bsrc[i]);
+        }
+        if (EPI) {
 #pragma unroll
-                for (int ct = 0; ct < TTW; ++ct) ec[ct] = en[ct], en[ct] = *reinterpret_cast<const uint16_t *>(ebase + (size_t)ct * 16 * erow + (size_t)n1 * 8 + eoff);
-            }
+            for (int ct = 0; ct < TTW; ++ct) ec[ct] = *reinterpret_cast<const uint16_t *>(lds + (blk & 1) * kBuf + eread + ct * 256);
         }
         // B operands one group (token tile, digit) ahead of their MFMAs: hipcc otherwise waits for every group's reads right after
         // issuing them; group 0 is requested ahead of the code expansion
@@ -1423,7 +1468,7 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
         __syncthreads();
     }
     if (EPI) {
-        f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, bx, by, rw, c, g, tid);
+        f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, mu_rs, bx, by, rw, c, g, tid);
         return;
     }
 #pragma unroll
@@ -1796,7 +1841,8 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
         fk = rt5 ? (fmt1 ? k_gemm_f16a<1, 4, 2, 5> : k_gemm_f16a<0, 4, 2, 5>) : (fmt1 ? k_gemm_f16a<1, 4, 2> : k_gemm_f16a<0, 4, 2>);
         a.qb_nblk_out = (int)(w.rows / 256);
         a.qb_out = static_cast<uint8_t *>(io.qb_out);
-        a.qb_exps_out = a.qb_out + m_pad * (size_t)a.qb_nblk_out * 576;
+        static const int qb_ablate = [] { const char *e = getenv("BITNET_HIP_QB_ABLATE"); return e ? atoi(e) : 0; }();
+        a.ablate = qb_ablate;
     }
     {
         static std::mutex f_mu;
@@ -1809,7 +1855,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
         }
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5, rt5 ? 80 : 64};
-    const size_t lds = (size_t)2 * ttw * 16 * 512;  // (the epilogue's 5 KiB of statistics scratch fit the smallest tile pair: 16 KiB)
+    const size_t lds = (size_t)2 * ttw * 16 * 512 + (size_t)ttw * 16 * 8;  // two tile buffers + the tokens' (mean, 1 / denom)
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, w.cols, fmt1);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
@@ -1817,14 +1863,15 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
 
 size_t qb32_bytes(size_t m, size_t cols) {
     const size_t m_pad = div_ceil(m, 64) * 64, nblk = div_ceil(cols, 256);
-    return m_pad * nblk * 576 + m_pad * nblk * 8 + 256;
+    return m_pad * nblk * kQbRec + 256;
 }
 
 hipError_t launch_rows_to_qb32(const float *x, const float *gamma, size_t m, size_t cols, void *qb, float *stats, hipStream_t stream) {
     if (cols % 256 != 0 || m == 0 || cols > 8192) return hipErrorInvalidValue;
     const size_t m_pad = div_ceil(m, 64) * 64, nblk = cols / 256;
     uint8_t *planes = static_cast<uint8_t *>(qb);
-    hipLaunchKernelGGL(k_rows_to_qb32, dim3((unsigned)m_pad), dim3(256), (cols / 32) * 144, stream, x, gamma, (int)m, (int)cols, planes, planes + m_pad * nblk * 576, stats);
+    (void)nblk;
+    hipLaunchKernelGGL(k_rows_to_qb32, dim3((unsigned)m_pad), dim3(256), (cols / 32) * 144, stream, x, gamma, (int)m, (int)cols, planes, stats);
     return hipGetLastError();
 }
 
@@ -1844,7 +1891,6 @@ hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hip
     a.nblk = (int)nblk;
     a.lut = w.lut;
     a.planes = static_cast<const int8_t *>(io.xh);
-    a.qb_exps = static_cast<const uint8_t *>(io.xh) + m_pad * nblk * 576;
     a.inv_scale = nullptr;
     a.y = io.y;
     a.m = (int)m;
@@ -1877,8 +1923,10 @@ hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hip
         }
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 8, rt5 ? 80 : 64, res ? 1 : 0};  // scale_mode 8: the fp6 form on QB32 rows
+    static const int qb_ablate = [] { const char *e = getenv("BITNET_HIP_QB_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = qb_ablate;
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);
-    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, a, lut_fp4(w.lut));
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * kQbRec + (size_t)ttw * 16 * 8, stream, a, lut_fp4(w.lut));
     return hipGetLastError();
 }
 

@@ -286,8 +286,8 @@ int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t w, const void *xh_dev, size_t
  * row quantiser needs the row maximum, which no producing workgroup has, so it stayed a launch of its own (two per layer, 6 % of the QK256
  * prompt).  The block-scaled MFMA takes one E8M0 scale per 32 K-slots of a token, so a QB32 row scales LOCALLY: per 32-column unit, E = exponent
  * of the unit's largest |v|, q = rint(v 2^(13 - E)) as three balanced base-32 fp6 digits (the 15-bit integer class of the 2-digit planes), one
- * exponent byte per unit.  Buffer: digit records [m_pad][cols / 256][576] then [m_pad][cols / 32] bytes, m_pad = m rounded up to 64
- * (bitnet_hip_qb32_bytes).  LayerNorm is applied after the product from the producer's statistics partials, as on the f16 chain.
+ * exponent byte per unit.  Buffer: records [m_pad][cols / 256] of 592 bytes (576 of digits, the block's 8 exponent bytes, 8 of padding), m_pad = m
+ * rounded up to 64 (bitnet_hip_qb32_bytes).  LayerNorm is applied after the product from the producer's statistics partials, as on the f16 chain.
  *   bitnet_hip_rows_to_qb32_dev: f32 rows -> QB32 of gamma * x (gamma nullable) + stats partial 0: the chain's entry (the embedding rows).
  *   bitnet_hip_matmul_f16_dev(..., flags | BITNET_HIP_FUSE_YH_QB32, yh_dev = a QB32 buffer of [m][rows], gamma_out, stats_out): the o- / down-
  *     projection's epilogue leaves gamma_out * y as QB32 rows (64-token tiles: m_pad / 64 * rows / 256 >= 256 workgroups; no FUSE_SILU_MUL).
