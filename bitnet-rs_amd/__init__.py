@@ -834,6 +834,10 @@ class HostDecoder:
         self._check(self.c.bitnet_host_prefill(self.h, n, int(with_logits), digits, C.byref(ms)))
         return ms.value
 
+    def last_prefill_path(self) -> int:
+        """What the last prefill() ran: 0 digit planes (+ f16 hand-over / hybrid o / down), 1 the f16 chain, 2 the QB32 chain."""
+        return int(self.c.bitnet_host_last_prefill_path(self.h))
+
     def position(self) -> int:
         return int(self.c.bitnet_host_position(self.h))
 

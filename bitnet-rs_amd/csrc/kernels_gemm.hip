@@ -65,7 +65,6 @@ struct GemmArgs {
     uint8_t *qb_out = nullptr;         // producer: records of the OUTPUT rows [m_pad][qb_nblk_out][592] (gamma_out * y, the next matmul's K = rows)
     int qb_nblk_out = 0;
     const uint8_t *tiles4 = nullptr;  // k_gemm_fp6<.., RES = 1>: the resident fp4 image [n_tiles][nblk][m 2][64][16] (k_retile_fp4)
-    int ablate = 0;  // developer timing only (BITNET_HIP_QB_ABLATE: wrong results): 1 no exponent loads, 2 no LayerNorm statistics, 4 no hand-over pack
     int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
 
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(256 * CW, MINW) void k_gemm_mfma(GemmArgs p) {
 // ================================================================================================================================
 // BitNet32-F16 (ternary codes x one f16 scale per 32 weights) on the f16 matrix cores: "2-bit weight unpack x f16 activation dot
 // product, per-block scale" as north_star words it.  The int8 digit form above has to fold every 32-block's integer sums into f32
-// with that block's scale -- 3 VALU per (row, token, block), 768 of the 980 VALU instructions of a K step -- which
+// with that block's scale -- 3 VALU per (row, token, block), 768 of the 980 VALU instructions of a K step (EXPERIMENTS 4.3) -- which
 // made the headline storage format prefill at HALF the QK256 rate.  Here the block scale is folded into the WEIGHT instead:
 // the A operand of v_mfma_f32_16x16x32_f16 is (+-s or 0) as f16 -- exact, s is an f16 value -- accumulating straight into the f32
 // accumulator of the whole K loop: no fold, no per-block epilogue, and one MFMA per (32 columns, row tile, token tile) instead of two
@@ -939,7 +938,11 @@ struct ChainLnStats {
             v[k] = *reinterpret_cast<const float2 *>(sp + 2 * (size_t)ic * p.stats_stride);  // (finish() zeroes the clamped ones: no use of the value here,
         }                                                                                  //  so no wait ahead of the tile loads that follow)
     }
-    __device__ __forceinline__ void finish(const GemmArgs &p, double *red, float2 *mu_rs, int tid) {
+    // sum(): this thread's partials added up and left in `red` (16 * NW * 64 bytes of LDS nobody else touches); NO barrier here: the caller's next
+    // barrier (the one that ends its prologue) orders it before final(), which the first WG_TOK threads run behind that barrier while the other
+    // waves go on into the K loop -- mu_rs is first read in the epilogue, behind every K step's barrier.  (As finish() with its own barrier
+    // in the prologue, every workgroup paid two barriers and a serial f64 section before its first MFMA.)
+    __device__ __forceinline__ void sum(const GemmArgs &p, double *red, int tid) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
@@ -957,9 +960,10 @@ struct ChainLnStats {
             for (int k = 0; k < 10; ++k) s1 += (double)v[k].x, s2 += (double)v[k].y;
         }
         red[2 * tid] = s1, red[2 * tid + 1] = s2;
-        __syncthreads();
+    }
+    __device__ __forceinline__ void final(const GemmArgs &p, const double *red, float2 *mu_rs, int tid) {
         if (tid < WG_TOK) {
-            s1 = s2 = 0.0;
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int q = 0; q < NG; ++q) s1 += red[2 * (q * WG_TOK + tid)], s2 += red[2 * (q * WG_TOK + tid) + 1];
             const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
@@ -1050,7 +1054,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                     float4{val[rt][0] * gout[rt][0], val[rt][1] * gout[rt][1], val[rt][2] * gout[rt][2], val[rt][3] * gout[rt][3]};
             }
         }
-        if (QB && (tt & 1) && !(p.ablate & 4)) {
+        if (QB && (tt & 1)) {
             constexpr int NU = NW * RT / 2;
             const float *st = reinterpret_cast<const float *>(lds + 8192);
             __syncthreads();
@@ -1144,10 +1148,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 #pragma unroll
         for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(bsrc[i] + (size_t)n1 * 512);
     }
-    // the input LayerNorm's (mean, 1 / denom) per token, behind the tile buffers; the reduction's scratch is tile buffer 1 (free until the barrier below)
+    // the input LayerNorm's (mean, 1 / denom) per token and the reduction's scratch, behind the tile buffers
     float2 *mu_rs = reinterpret_cast<float2 *>(lds + 2 * kBuf);
-    if (ln_in) lnst.finish(p, reinterpret_cast<double *>(lds + kBuf), mu_rs, tid);
+    double *ln_red = reinterpret_cast<double *>(lds + 2 * kBuf + WG_TOK * 8);
+    if (ln_in) lnst.sum(p, ln_red, tid);
     __syncthreads();
+    if (ln_in) lnst.final(p, ln_red, mu_rs, tid);
 
 #ifdef BH_STAMPS
     // phase cycles of this wave (s_memtime), summed over the K steps: 0 staging stores (incl. their wait for the tile's loads), 1 issuing
@@ -1269,7 +1275,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
 // below 2^24 (|w q| <= 2^15 per term: a sum only leaves that range when more than 512 terms line up at full scale; past it the
 // accumulator rounds like any f32 sum, 2^-24 relative).  So this form computes the SAME integer as k_gemm_mfma<2, ...> from the SAME
 // quantised q (k_quant_rows<2, NV, 1>) with 3 MFMAs per 128 columns instead of 4, half the accumulator registers, and multipliers a
-// fraction of the int8 ones' size (the int8 loop runs at a power limit: DESIGN 4.5; tools/probes/mfma_fp6_probe.hip).
+// fraction of the int8 ones' size (the int8 loop runs at a power limit: EXPERIMENTS 4.5; tools/probes/mfma_fp6_probe.hip).
 // Operands: lane (row r, group g) of a streaming tile holds the 64 codes of columns 64 g .. 64 g + 63; MFMA m = 0, 1 takes dwords
 // 2 m, 2 m + 1 expanded to 32 fp4 nibbles (expand16_fp4: k-slot 8 q + n = column 64 g + 32 m + 8 q + 4 (n & 1) + (n >> 1)); the
 // B operand of lane (token c, group g) is the 24 bytes the quantiser wrote for (g, digit, m) in that slot order.
@@ -1307,9 +1313,11 @@ __global__ void k_retile_fp4(const uint8_t *__restrict__ tiles, uint8_t *__restr
 // EPI = 1: QB32 activations in (per-unit exponent bytes beside the digit records: the B scale operand is per lane) and the f16 chain's epilogue out
 // (LayerNorm after the product from the producer's statistics partials, residual, silu * up as f16 rows, f32 rows).
 template <int TTW, int RT = 4, int RES = 0, int EPI = 0>
-__global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {
+__global__ __launch_bounds__(256, (TTW >= 4 || EPI) ? 2 : TTW == 2 ? 3 : 4) void k_gemm_fp6(GemmArgs p, uint32_t lut4) {  // (the chain epilogue's narrow forms spill under 3 / 4 waves per SIMD)
     // EPI: QB32 records (kQbRec = 592 bytes): unit 36 of a token's record holds the block's eight exponent bytes and is staged behind the digit tile
-    constexpr int T = 16 * TTW, REC = EPI ? kQbRec : 576, UPT = REC / 16, UNITS = T * UPT, NB = (UNITS + 255) / 256, kDig = T * 576, kBuf = kDig + (EPI ? T * 16 : 0);
+    // (the digit tile is staged as 36 sixteen-byte units per token by all threads; the exponent bytes as ONE 8-byte piece per token by the first T threads:
+    //  as a 37th unit they made every thread's tenth load / store per K step -- 11 % more staging for 1.4 % more payload, and the launch 10 % slower)
+    constexpr int T = 16 * TTW, REC = EPI ? kQbRec : 576, UNITS = T * 36, NB = (UNITS + 255) / 256, kDig = T * 576, kBuf = kDig + (EPI ? T * 8 : 0);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile bases below stay in SGPRs)
     const int c = lane & 15, g = lane >> 4, rw = wave;
@@ -1349,12 +1357,16 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
     for (int i = 0; i < NB; ++i) {
         int idx = tid + 256 * i;
         idx = idx < UNITS ? idx : UNITS - 1;  // (surplus threads of the last round repeat its last unit: same bytes, same place)
-        const int tok = idx / UPT, u = idx % UPT, gg = u / 9, k = u % 9;
+        const int tok = idx / 36, u = idx % 36, gg = u / 9, k = u % 9;
         bsrc[i] = (uint32_t)tok * row_bytes + (uint32_t)u * 16u;
-        bdst[i] = u < 36 ? ((gg * T + tok) * 9 + k) * 16 : kDig + tok * 16;
+        bdst[i] = ((gg * T + tok) * 9 + k) * 16;
     }
+    const bool e_thr = EPI && tid < T;  // this thread stages token tid's eight exponent bytes
+    const uint32_t esrc = (uint32_t)(tid < T ? tid : 0) * row_bytes + 576u;
+    typedef unsigned gv2u __attribute__((ext_vector_type(2)));
+    gv2u exn = {0u, 0u};
     ChainLnStats<T, 4> lnst;
-    const bool ln_in = EPI && p.stats_in && !(p.ablate & 2);
+    const bool ln_in = EPI && p.stats_in;
     if (ln_in) lnst.issue(p, by, tid);
     gv4f acc[RT][TTW];
 #pragma unroll
@@ -1368,20 +1380,25 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
         for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + m * 1024 + woff);
 #pragma unroll
     for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + bsrc[i]);
+    if (e_thr) exn = *reinterpret_cast<const gv2u *>(abase + esrc);
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(lds + bdst[i]) = bn[i];
+    if (e_thr) *reinterpret_cast<gv2u *>(lds + kDig + tid * 8) = exn;
     {
         const int n1 = p.nblk > 1 ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n1 * REC + bsrc[i]);
+        if (e_thr) exn = *reinterpret_cast<const gv2u *>(abase + (size_t)n1 * REC + esrc);
     }
-    // (EPI) the input LayerNorm's (mean, 1 / denom) per token, behind the tile buffers; scratch = tile buffer 1, free until the barrier below
+    // (EPI) the input LayerNorm's (mean, 1 / denom) per token and the reduction's scratch, behind the tile buffers
     float2 *mu_rs = reinterpret_cast<float2 *>(lds + 2 * kBuf);
-    if (ln_in) lnst.finish(p, reinterpret_cast<double *>(lds + kBuf), mu_rs, tid);
+    double *ln_red = reinterpret_cast<double *>(lds + 2 * kBuf + T * 8);
+    if (ln_in) lnst.sum(p, ln_red, tid);
     __syncthreads();
+    if (ln_in) lnst.final(p, ln_red, mu_rs, tid);
     const int bread = (g * T + c) * 144;
     // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) per token tile and K step, requested one step ahead
-    const int eread = kDig + c * 16 + 2 * g;  // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) of token tile ct: + 256 ct
+    const int eread = kDig + c * 8 + 2 * g;  // QB32: this lane's two exponent bytes (units m = 0, 1 of lane group g) of token tile ct: + 128 ct
     uint32_t ec[TTW];
 #pragma unroll
     for (int ct = 0; ct < TTW; ++ct) ec[ct] = 0u;
@@ -1392,6 +1409,7 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
         if (blk + 1 < p.nblk) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) *reinterpret_cast<gv4u *>(nxt + bdst[i]) = bn[i];
+            if (e_thr) *reinterpret_cast<gv2u *>(nxt + kDig + tid * 8) = exn;
         }
         gv4u wc[NM][RT];
 #pragma unroll
@@ -1406,13 +1424,14 @@ __global__ __launch_bounds__(256, TTW >= 4 ? 2 : TTW == 2 ? 3 : 4) void k_gemm_f
                 for (int m = 0; m < NM; ++m) wn[m][rt] = *reinterpret_cast<const gv4u *>(wptr[rt] + (size_t)n1 * WSTEP + m * 1024 + woff);
 #pragma unroll
             for (int i = 0; i < NB; ++i) bn[i] = *reinterpret_cast<const gv4u *>(abase + (size_t)n2 * REC + bsrc[i]);
+            if (e_thr) exn = *reinterpret_cast<const gv2u *>(abase + (size_t)n2 * REC + esrc);
         }
         if (EPI) {
 #pragma unroll
-            for (int ct = 0; ct < TTW; ++ct) ec[ct] = *reinterpret_cast<const uint16_t *>(lds + (blk & 1) * kBuf + eread + ct * 256);
+            for (int ct = 0; ct < TTW; ++ct) ec[ct] = *reinterpret_cast<const uint16_t *>(lds + (blk & 1) * kBuf + eread + ct * 128);
         }
         // B operands one group (token tile, digit) ahead of their MFMAs: hipcc otherwise waits for every group's reads right after
-        // issuing them; group 0 is requested ahead of the code expansion
+        // issuing them (EXPERIMENTS 4.5, VAR2); group 0 is requested ahead of the code expansion
         // (the wide tile only: the 5-tile and the narrow forms have no registers to spare for the second operand set)
         constexpr int NG = TTW * 3;
         constexpr bool PIPE = TTW == 4 && RT == 4;
@@ -1560,7 +1579,7 @@ static bool gemm_five_tiles(size_t rows, size_t m_pad) {
     const size_t slots = 2 * kGemmCUs, tb = m_pad / 64;
     return div_ceil(rows / 320 * tb, slots) * 5 < div_ceil(div_ceil(rows, 256) * tb, slots) * 4;
 }
-// Weight-stationary walk of a launch.  In the plain order an XCD takes a band of token tiles and walks ALL row blocks for each: the
+// Weight-stationary walk of a launch (EXPERIMENTS 4.6).  In the plain order an XCD takes a band of token tiles and walks ALL row blocks for each: the
 // activation tile stays in its L2, the whole weight matrix streams through once per token tile (gate|up: 8.85 MB x 64 tiles = 566 MB of L2 misses
 // per launch, served by the Infinity Cache).  Grouped, an XCD takes `wgroup` row blocks -- the largest divisor of the row-block count whose codes
 // (+ scales) stay within 1.5 MiB of its 4 MiB L2 -- walks every token tile for them, then the next group: the weights are fetched about once, the
@@ -1841,8 +1860,6 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
         fk = rt5 ? (fmt1 ? k_gemm_f16a<1, 4, 2, 5> : k_gemm_f16a<0, 4, 2, 5>) : (fmt1 ? k_gemm_f16a<1, 4, 2> : k_gemm_f16a<0, 4, 2>);
         a.qb_nblk_out = (int)(w.rows / 256);
         a.qb_out = static_cast<uint8_t *>(io.qb_out);
-        static const int qb_ablate = [] { const char *e = getenv("BITNET_HIP_QB_ABLATE"); return e ? atoi(e) : 0; }();
-        a.ablate = qb_ablate;
     }
     {
         static std::mutex f_mu;
@@ -1855,7 +1872,7 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
         }
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5, rt5 ? 80 : 64};
-    const size_t lds = (size_t)2 * ttw * 16 * 512 + (size_t)ttw * 16 * 8;  // two tile buffers + the tokens' (mean, 1 / denom)
+    const size_t lds = (size_t)2 * ttw * 16 * 512 + (size_t)ttw * 16 * 8 + 4096;  // two tile buffers + the tokens' (mean, 1 / denom) + the statistics scratch
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, w.cols, fmt1);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
@@ -1907,11 +1924,10 @@ hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hip
     a.stats_out = io.stats_out;
     size_t gx0 = w.rows / 256;
     const int ttw = gemm_token_tiles(gx0, m_pad, false);
-    const bool rt5 = ttw == 4 && !io.silu_mul && gemm_five_tiles(w.rows, m_pad);
-    if (rt5) gx0 = w.rows / 320;
+    const bool rt5 = false;  // (the 320-row form of this variant does not fit 256 registers: hipcc spills 80 bytes; the model's QB32 consumers -- 3840 and 13824 rows -- take four tiles anyway)
     const bool res = a.tiles4 != nullptr;
-    void (*fk)(GemmArgs, uint32_t) = res ? (rt5 ? k_gemm_fp6<4, 5, 1, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 1, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 1, 1> : k_gemm_fp6<1, 4, 1, 1>)
-                                         : (rt5 ? k_gemm_fp6<4, 5, 0, 1> : ttw == 4 ? k_gemm_fp6<4, 4, 0, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 0, 1> : k_gemm_fp6<1, 4, 0, 1>);
+    void (*fk)(GemmArgs, uint32_t) = res ? (ttw == 4 ? k_gemm_fp6<4, 4, 1, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 1, 1> : k_gemm_fp6<1, 4, 1, 1>)
+                                         : (ttw == 4 ? k_gemm_fp6<4, 4, 0, 1> : ttw == 2 ? k_gemm_fp6<2, 4, 0, 1> : k_gemm_fp6<1, 4, 0, 1>);
     {
         static std::mutex f_mu;
         static std::unordered_set<const void *> f_raised;
@@ -1923,10 +1939,8 @@ hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hip
         }
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 8, rt5 ? 80 : 64, res ? 1 : 0};  // scale_mode 8: the fp6 form on QB32 rows
-    static const int qb_ablate = [] { const char *e = getenv("BITNET_HIP_QB_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = qb_ablate;
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);
-    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * kQbRec + (size_t)ttw * 16 * 8, stream, a, lut_fp4(w.lut));
+    hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * (576 + 8) + (size_t)ttw * 16 * 8 + 4096, stream, a, lut_fp4(w.lut));
     return hipGetLastError();
 }
 

@@ -843,12 +843,14 @@ int Decoder::prefill_chain_layers(size_t N) {
 // fixed point, one exponent per 32 columns of a token -- that the kernel PRODUCING the residual stream wrote: the o- / down-projection (f16 matrix
 // cores, 320-row workgroups: the hybrid forward's launches) leaves x (f32), QB32(gamma_next * x) and the LayerNorm statistics partials in its
 // epilogue (BITNET_HIP_FUSE_YH_QB32); LayerNorm is applied after the product (as on the f16 chain and in the decode step).  Only where the hybrid
-// forward applies (long prompts: the producers then run 64-token tiles) and every q|k|v / gate|up matrix takes the form; BITNET_HOST_PREFILL_QB32=0
-// restores the quantiser launches.
+// forward applies (long prompts: the producers then run 64-token tiles) and every q|k|v / gate|up matrix takes the form.  OPT-IN
+// (BITNET_HOST_PREFILL_QB32=1): measured same-box it is a tie with the quantiser launches (18.91-18.93 vs 18.97-19.00 ms at 4096 tokens: the 41.5 us of
+// quantisers per layer come back as +17 / +6.5 us in gate|up / q|k|v and +9 us per producing launch -- the prompt forward runs at a power limit, and the
+// memory-bound quantisers were also the matrix pipes' rest: EXPERIMENTS 8.3), and the default keeps the form that is bit-identical to the int8 planes.
 bool Decoder::qb32_applies(int digits, size_t n_rows) {
     if (prefill_qb32_ < 0) {
         const char *e = getenv("BITNET_HOST_PREFILL_QB32");
-        prefill_qb32_ = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+        prefill_qb32_ = e ? (atoi(e) != 0 ? 1 : 0) : 0;
     }
     if (!prefill_qb32_ || digits != 2 || !handover16_applies(digits) || !hybrid_applies(n_rows) || !fp6_flag(digits)) return false;
     for (const auto &L : layers_)
@@ -951,6 +953,7 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         const int rc = prefill_qb32_layers(N);
         if (rc) return rc;
     }
+    last_prefill_path_ = chain ? 1 : qb ? 2 : 0;
     const bool h16 = !chain && !qb && handover16_applies(digits);
     if (h16) {
         const int rc = ensure_chain_buffers(N);
@@ -1496,6 +1499,7 @@ void bitnet_host_global_objects(void *d, void **ptrs7) {
     if (Decoder *D = live(d)) D->global_objects(ptrs7);
 }
 int bitnet_host_position(void *d) { LIVE(-1); return D->position(); }
+int bitnet_host_last_prefill_path(void *d) { LIVE(-1); return D->last_prefill_path(); }
 int bitnet_host_history(void *d, int32_t *out, int n) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->history(out, n); }
 int bitnet_host_last_logits(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_logits(out); }
 int bitnet_host_last_hidden(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_hidden(out); }

@@ -225,7 +225,7 @@ int bitnet_hip_matmul_kernel_dev(bitnet_hip_weights_t w, const float *x_dev, flo
  *     activation as three base-32 digits on the block-scaled fp6 x fp4 MFMA (k_gemm_fp6: same products, f32 accumulation of exact
  *     integers -- bit-identical to the int8 form while every partial sum stays below 2^24); also the process default with
  *     BITNET_HIP_GEMM_FP6=1.  Measured: 10-14 % faster per gate|up / down launch under sustained load, its quantiser 9-20 us slower
- *     per launch: about even inside a prompt, hence opt-in.  Round 5: the weight operands come from the resident fp4 image
+ *     per launch: about even inside a prompt, hence opt-in (EXPERIMENTS 4.6).  Round 5: the weight operands come from the resident fp4 image
  *     (bitnet_hip_weights_fp4_image, built on first use) unless
  *   BITNET_HIP_FUSE_FP6_EXPAND is set too: the fp6 form expanding the 2-bit streaming tiles in its K loop (no image is built or read) */
 #define BITNET_HIP_FUSE_X_F16 2

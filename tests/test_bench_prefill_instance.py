@@ -343,3 +343,34 @@ def test_prefill_2_digits_then_decode_matches_oracle_1k_and_4k(pkg, hip, oracle,
         assert list(dec.history(T + n_new)) == [int(t) for t in seq], kv16
     assert cosine(hidden[False], hidden[True]) >= 0.99999  # the prompt attention is f16 on the matrix cores either way
     dec.close()
+    if fmt != "qk256":
+        return
+    # ---- the QB32 chain (opt-in, round 5: no row quantiser launch; q|k|v and gate|up on producer-quantised block-scaled rows, LayerNorm after
+    # the product): the same prompt, the same oracle logits, the same greedy tokens
+    import os
+
+    os.environ["BITNET_HOST_PREFILL_QB32"] = "1"  # read by a Decoder at its first prefill
+    try:
+        dec = pkg.HostDecoder(cfg)
+        for l, w in enumerate(layers):
+            dec.set_layer_qk256(l, w)
+        dec.set_globals(glob)
+        dec.reset()
+        dec.set_kv_f16(True)
+        dec.feed(seq)
+        dec.prefill(T, with_logits=True, digits=2)
+        assert dec.last_prefill_path() == 2
+        c = cosine(dec.last_logits(), o_logits[0])
+        assert c >= 0.9999, c
+        assert cosine(dec.last_hidden(), hidden[True]) >= 0.9999
+        for i in range(1, n_new):
+            dec.run(1, with_logits=True, use_graph=True)
+            assert cosine(dec.last_logits(), o_logits[i]) >= 0.9999, i
+        assert list(dec.history(T + n_new)) == [int(t) for t in seq]
+        dec.reset()
+        dec.feed(prompt[:1024])
+        dec.prefill(1024, with_logits=True, digits=2)  # short prompts keep the quantiser launches (the producers' 64-token tiles need the hybrid forward)
+        assert dec.last_prefill_path() == 0 and cosine(dec.last_logits(), o_1k) >= 0.9999
+        dec.close()
+    finally:
+        del os.environ["BITNET_HOST_PREFILL_QB32"]

@@ -31,7 +31,10 @@ GEMMF16 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1ELi4EEEvNS_8GemmArgsEj"  # th
 # the 320-row workgroups of the 2560-row launches (five row tiles per wave), BitNet32-F16 and QK256 (the hybrid prompt forward's o / down)
 GEMMF16_R5 = "_ZN10bitnet_hip11k_gemm_f16aILi1ELi4ELi1ELi5EEEvNS_8GemmArgsEj"
 GEMMF16_R5_QK = "_ZN10bitnet_hip11k_gemm_f16aILi0ELi4ELi1ELi5EEEvNS_8GemmArgsEj"
-GEMMFP6 = "_ZN10bitnet_hip10k_gemm_fp6ILi4ELi4EEEvNS_8GemmArgsEj"  # the fp6 x fp4 form, 64-token tile (opt-in)
+GEMMFP6 = "_ZN10bitnet_hip10k_gemm_fp6ILi4ELi4ELi1ELi0EEEvNS_8GemmArgsEj"  # the fp6 x fp4 form on the resident fp4 image, 64-token tile (QK256 q|k|v, gate|up: round 5's default)
+GEMMFP6_X = "_ZN10bitnet_hip10k_gemm_fp6ILi4ELi4ELi0ELi0EEEvNS_8GemmArgsEj"  # ... expanding the 2-bit tiles in its K loop (BITNET_HIP_FUSE_FP6_EXPAND)
+GEMMFP6_QB = "_ZN10bitnet_hip10k_gemm_fp6ILi4ELi4ELi1ELi1EEEvNS_8GemmArgsEj"  # ... on QB32 rows with the chain epilogue (opt-in)
+GEMMF16_QB = "_ZN10bitnet_hip11k_gemm_f16aILi0ELi4ELi2ELi5EEEvNS_8GemmArgsEj"  # the o- / down-projection handing QB32 rows over (opt-in)
 
 
 def _compile(src, tmp):
@@ -101,7 +104,7 @@ def test_resources_of_the_benchmarked_instantiations(isa):
     _, ua = isa["kernels_prefill_attn.hip"]
     _, ug = isa["kernels_gemm.hip"]
     for name, usage, ceiling in ((ATTN, ua, 230), (GEMM64, ug, 232), (GEMM32, ug, 168), (GEMMF16, ug, 200), (GEMMF16_R5, ug, 224), (GEMMF16_R5_QK, ug, 208),
-                                 (GEMMFP6, ug, 240)):
+                                 (GEMMFP6, ug, 244), (GEMMFP6_X, ug, 232), (GEMMFP6_QB, ug, 254), (GEMMF16_QB, ug, 254)):
         u = usage[name]
         assert u["ScratchSize"] == 0, (name, u)
         assert u["VGPRs"] + u.get("AGPRs", 0) <= ceiling, (name, u)

@@ -5,7 +5,7 @@
 // the int8 form for K = 64.  A 15-bit activation is three base-32 digits whose weights 1, 32, 1024 ride in the instruction's E8M0
 // block scale, so the three digit products accumulate into ONE f32 accumulator: 3 MFMAs per 128 columns instead of 4 (two int8
 // digits x two K = 64 steps), half the accumulator registers, and far narrower multipliers (MI355X lowers its clock by switching
-// activity: DESIGN 4.5).
+// activity: EXPERIMENTS 4.5).
 //
 // Part 1 checks the operand maps with exact integer data against a host loop:
 //   lane l = (r = l & 15, g = l >> 4) holds A[row r][k = 32 g + j] / B[k = 32 g + j][col r], j = 0..31, element j at bits
