@@ -341,6 +341,11 @@ class HipLib:
         self._check(self.c.bitnet_hip_matmul_f16_dev(h, _ptr(xh), m, _optr(stats_in), n_stats, _optr(ln_gamma), ln_eps, _optr(y), _optr(residual), flags,
                                                      _optr(yh), _optr(gamma_out), _optr(stats_out), _vp(stream)))
 
+    def f16_saturations(self, reset: bool = True) -> int:
+        self.c.bitnet_hip_f16_saturations.restype = C.c_uint64
+        self.c.bitnet_hip_f16_saturations.argtypes = [C.c_int]
+        return int(self.c.bitnet_hip_f16_saturations(1 if reset else 0))
+
     # ---- QB32: producer-quantised rows for the fp6 x fp4 prompt matmul (include/bitnet_hip.h) ----
     def qb32_bytes(self, m: int, cols: int) -> int:
         self.c.bitnet_hip_qb32_bytes.restype = _sz
@@ -699,6 +704,8 @@ class HostDecoder:
         L.bitnet_host_set_act_mode.argtypes = [C.c_void_p, C.c_int]
         L.bitnet_host_act_mode.argtypes = [C.c_void_p]
         L.bitnet_host_position.argtypes = [C.c_void_p]
+        L.bitnet_host_last_prefill_path.argtypes = [C.c_void_p]
+        L.bitnet_host_saturation_fallbacks.argtypes = [C.c_void_p]
         L.bitnet_host_history.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bitnet_host_last_logits.argtypes = [C.c_void_p, _f32p]
         L.bitnet_host_last_hidden.argtypes = [C.c_void_p, _f32p]
@@ -837,6 +844,10 @@ class HostDecoder:
     def last_prefill_path(self) -> int:
         """What the last prefill() ran: 0 digit planes (+ f16 hand-over / hybrid o / down), 1 the f16 chain, 2 the QB32 chain."""
         return int(self.c.bitnet_host_last_prefill_path(self.h))
+
+    def saturation_fallbacks(self) -> int:
+        """Prompts this decoder repeated on the row-scaled forms because an f16 hand-over value was clamped (bitnet_hip_f16_saturations)."""
+        return int(self.c.bitnet_host_saturation_fallbacks(self.h))
 
     def position(self) -> int:
         return int(self.c.bitnet_host_position(self.h))

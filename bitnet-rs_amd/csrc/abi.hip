@@ -600,6 +600,8 @@ int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t h, const void *xh_dev, size_t
     BH_GUARD_END
 }
 
+unsigned long long bitnet_hip_f16_saturations(int reset) { return f16_saturations(reset != 0); }
+
 size_t bitnet_hip_qb32_bytes(size_t m, size_t cols) { return qb32_bytes(m, cols); }
 
 int bitnet_hip_rows_to_qb32_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *qb_dev, float *stats_dev, void *stream) {

@@ -201,6 +201,7 @@ bool gemm_qb32_supported(const Weights &w);
 // the fp6 x fp4 form on QB32 rows (io.xh = the QB32 buffer) with the f16 chain's epilogue (LayerNorm after the product, residual, silu * up -> f16 rows)
 hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream);
 bool gemm_f16_chain_supported(const Weights &w);
+unsigned long long f16_saturations(bool reset);  // f16 hand-over values clamped to +-65504 since the last reset (lanes, not elements); synchronises the device
 hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m, hipStream_t stream);
 hipError_t launch_rows_to_f16(const float *x, const float *gamma, size_t m, size_t cols, void *xh, float *stats, hipStream_t stream);
 hipError_t launch_gemm_mfma(const Weights &w, const float *x, float *y, size_t m, const GemvFusion &fu, int ndig,

@@ -303,6 +303,26 @@ __device__ __forceinline__ void store_out4(float *dst, float a, float b, float c
     __builtin_nontemporal_store((gv4f){a, b, c, d}, reinterpret_cast<gv4f *>(dst));
 }
 
+// f16 hand-over rows are clamped to +-65504 (an f16 element carries its own exponent: no row scale).  A clamp is COUNTED, not silent: the
+// decoder reads the counter behind a prompt forward and repeats the prompt on the row-scaled forms when it is not zero (Decoder::prefill).
+__device__ unsigned int g_f16_saturations = 0;
+__device__ __forceinline__ _Float16 gclamp_f16(float v, bool &sat) {
+    sat = sat || !(fabsf(v) <= 65504.0f);  // (also true for NaN)
+    return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+}
+__device__ __forceinline__ void gflush_sat(bool sat) {
+    if (sat) atomicAdd(&g_f16_saturations, 1u);  // (rare: one atomic per lane that clamped, none otherwise)
+}
+unsigned long long f16_saturations(bool reset) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_saturations), sizeof(v)) != hipSuccess) return ~0ull;  // (synchronises the device)
+    if (reset && v) {
+        const unsigned int z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_saturations), &z, sizeof(z));
+    }
+    return v;
+}
+
 // silu(gate) * up (FeedForward::forward T:756-781, silu(v) = v / (1 + exp(-v))) as the decode GEMV's epilogue computes it (kernels_gemvq.hip):
 // v_exp_f32 + v_rcp_f32, 6 VALU per output.  The IEEE division and libm expf of the first version were ~22 VALU per output: 700 of the ~1400
 // VALU instructions of a gate|up wave's epilogue, which no MFMA of that wave overlaps.  |error| ~ 1e-6 relative (the f16 hand-over rounds at 5e-4).
@@ -372,8 +392,10 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     sh4 o;
+                    bool sat = false;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[pr][j], -65504.0f, 65504.0f);
+                    for (int j = 0; j < 4; ++j) o[j] = gclamp_f16(r[pr][j], sat);
+                    gflush_sat(sat);
                     *reinterpret_cast<sh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
                 }
             }
@@ -991,6 +1013,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
         gout[rt][0] = go.x, gout[rt][1] = go.y, gout[rt][2] = go.z, gout[rt][3] = go.w;
     }
     typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+    bool sat = false;  // an f16 hand-over value of a live token was clamped (counted once per lane at the end)
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
         const int tok0 = (by * TTW + tt) * 16, token = tok0 + c;
@@ -1018,7 +1041,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                     if (p.yh) {
                         gh4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(r[j], -65504.0f, 65504.0f);
+                        for (int j = 0; j < 4; ++j) o[j] = gclamp_f16(r[j], sat);
                         *reinterpret_cast<gh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
                     }
                     if (p.y) store_out4(p.y + (size_t)token * half_rows + ra + 16 * pr, r[0], r[1], r[2], r[3]);
@@ -1042,7 +1065,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                 if (p.yh) {
                     gh4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)__builtin_amdgcn_fmed3f(val[rt][j] * gout[rt][j], -65504.0f, 65504.0f);
+                    for (int j = 0; j < 4; ++j) o[j] = gclamp_f16(val[rt][j] * gout[rt][j], sat);
                     *reinterpret_cast<gh4 *>(p.yh + off) = o;
                 }
             }
@@ -1075,6 +1098,7 @@ __device__ __forceinline__ void f16_chain_epilogue(const GemmArgs &p, gv4f (&acc
                 *reinterpret_cast<float2 *>(p.stats_out + 2 * ((size_t)(NW * gridDim.x + bx * (NW / 4) + rw) * p.stats_stride + token)) = float2{0.f, 0.f};
         }
     }
+    gflush_sat(sat);
 }
 
 // RT = row tiles per wave: 4 (256-row workgroups), or 5 (320-row workgroups, chain form only): a 2560-row matrix x 4096 tokens is then
@@ -1535,8 +1559,9 @@ __global__ __launch_bounds__(256) void k_rows_to_f16(const float *__restrict__ x
             v.x *= gm.x, v.y *= gm.y, v.z *= gm.z, v.w *= gm.w;
         }
         typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
-        const gh4 o = {(_Float16)__builtin_amdgcn_fmed3f(v.x, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(v.y, -65504.0f, 65504.0f),
-                       (_Float16)__builtin_amdgcn_fmed3f(v.z, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(v.w, -65504.0f, 65504.0f)};
+        bool sat = false;
+        const gh4 o = {gclamp_f16(v.x, sat), gclamp_f16(v.y, sat), gclamp_f16(v.z, sat), gclamp_f16(v.w, sat)};
+        gflush_sat(sat && live);
         *reinterpret_cast<gh4 *>(xh + (size_t)row * cols + 4 * i) = o;
     }
     s1 = qwave_sum_d(s1), s2 = qwave_sum_d(s2);

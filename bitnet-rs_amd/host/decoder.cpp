@@ -725,7 +725,7 @@ int Decoder::run(int n, bool with_logits, bool use_graph, float *elapsed_ms) {
 // block-scaled format, whose matmul runs on f16 activations anyway; BITNET_HOST_PREFILL_CHAIN=1 forces it for QK256 (whose int8 digit
 // matmul is the faster kernel: the default there stays the digit planes), =0 switches it off.
 bool Decoder::chain_applies(int digits) const {
-    if (digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
+    if (force_scaled_ || digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
     bool scaled_all = true;
     for (const auto &L : layers_) {
         for (bitnet_hip_weights_t h : {L.qkv, L.o, L.gateup, L.down})
@@ -742,7 +742,7 @@ bool Decoder::chain_applies(int digits) const {
 // (BITNET_HIP_FUSE_X_F16 / _Y_F16): half the bytes on both sides of the two largest hand-overs.  digits = 2 only (an f16 row holds 11
 // bits of each element: more than the 2-digit planes take from most elements, fewer than 3 or 4 digits).
 bool Decoder::handover16_applies(int digits) const {
-    if (digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
+    if (force_scaled_ || digits != 2 || prefill_chain_ == 0 || layers_.empty()) return false;
     for (const auto &L : layers_)
         for (bitnet_hip_weights_t h : {L.o, L.gateup, L.down}) {
             size_t rows = 0, cols = 0, ab = 0;
@@ -852,7 +852,7 @@ bool Decoder::qb32_applies(int digits, size_t n_rows) {
         const char *e = getenv("BITNET_HOST_PREFILL_QB32");
         prefill_qb32_ = e ? (atoi(e) != 0 ? 1 : 0) : 0;
     }
-    if (!prefill_qb32_ || digits != 2 || !handover16_applies(digits) || !hybrid_applies(n_rows) || !fp6_flag(digits)) return false;
+    if (force_scaled_ || !prefill_qb32_ || digits != 2 || !handover16_applies(digits) || !hybrid_applies(n_rows) || !fp6_flag(digits)) return false;
     for (const auto &L : layers_)
         for (bitnet_hip_weights_t h : {L.qkv, L.gateup})
             if (!h || bitnet_hip_matmul_qb32_supported(h) != 1) return false;
@@ -940,6 +940,7 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
     HCHK(hipEventCreate(&ev0.e));
     HCHK(hipEventCreate(&ev1.e));
     hipEvent_t e0 = ev0.e, e1 = ev1.e;
+    if (!force_scaled_) (void)bitnet_hip_f16_saturations(1);  // a fresh count for this prompt
     HCHK(hipEventRecord(e0, s));
     const size_t N = (size_t)n;
     BCHK(bitnet_hip_embed_f16_dev(embed_, history_, pos_, N, H, (size_t)c_.vocab, pf_x_, s));  // *pos_ == 0
@@ -995,6 +996,20 @@ int Decoder::prefill(int n, bool with_logits, int digits, float *elapsed_ms) {
         BCHK(bitnet_hip_matmul_fused_dev(L.gateup, pf_x_, pf_h_, N, L.ffn_norm, c_.eps, nullptr, BITNET_HIP_FUSE_SILU_MUL | f6, digits, pf_gemm_ws_,
                                          pf_gemm_ws_bytes_, s));
         BCHK(bitnet_hip_matmul_fused_dev(L.down, pf_h_, pf_x_, N, nullptr, 0.f, pf_x_, 0, digits, pf_gemm_ws_, pf_gemm_ws_bytes_, s));
+    }
+    if (chain || qb || h16) {
+        // f16 hand-over rows carry no row scale: a value beyond +-65504 (outlier channels x gamma: none in the synthetic models, possible in a real
+        // checkpoint) is clamped AND counted (bitnet_hip_f16_saturations).  A prompt that clamped anything is repeated on the digit planes --
+        // 30-bit fixed point behind a per-row power-of-two scale (digits = 4: a row whose outlier is 10^5 times its typical element still keeps 13 bits of
+        // those; the 2-digit and row-scaled f16 forms would flush them) -- before its logits are taken (no silent saturation).
+        HCHK(hipStreamSynchronize(s));
+        if (bitnet_hip_f16_saturations(1) > 0) {
+            force_scaled_ = true;
+            ++saturation_fallbacks_;
+            const int rc = prefill(n, with_logits, 4, elapsed_ms);
+            force_scaled_ = false;
+            return rc;
+        }
     }
     {
         const int rc = finish_prefill(n, pf_x_ + (N - 1) * H, with_logits);
@@ -1500,6 +1515,7 @@ void bitnet_host_global_objects(void *d, void **ptrs7) {
 }
 int bitnet_host_position(void *d) { LIVE(-1); return D->position(); }
 int bitnet_host_last_prefill_path(void *d) { LIVE(-1); return D->last_prefill_path(); }
+int bitnet_host_saturation_fallbacks(void *d) { LIVE(-1); return D->saturation_fallbacks(); }
 int bitnet_host_history(void *d, int32_t *out, int n) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->history(out, n); }
 int bitnet_host_last_logits(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_logits(out); }
 int bitnet_host_last_hidden(void *d, float *out) { LIVE(BITNET_HIP_ERR_INVALID_ARGUMENT); return D->last_hidden(out); }

@@ -118,6 +118,7 @@ class Decoder {
     bool handover16_applies(int digits) const;
     bool hybrid_applies(size_t n_rows) const;
     int last_prefill_path() const { return last_prefill_path_; }
+    int saturation_fallbacks() const { return saturation_fallbacks_; }
     int fp6_flag(int digits);  // BITNET_HIP_FUSE_FP6_DIGITS for the q|k|v and gate|up launches of the digit-plane prompt forward, or 0
     int ensure_chain_buffers(size_t N);
     int prefill_chain_layers(size_t N);
@@ -218,6 +219,8 @@ class Decoder {
     float *pf_stats_ = nullptr;
     void *pf_qb_ = nullptr;   // QB32 rows of gamma * x (the input of q|k|v and of gate|up), bitnet_hip_qb32_bytes(pfc_cap_, hidden)
     int pf_qb_cap_ = 0;
+    bool force_scaled_ = false;   // the prompt is being repeated on the row-scaled forms after an f16 hand-over value was clamped (prefill)
+    int saturation_fallbacks_ = 0;
     int last_prefill_path_ = 0;  // what the last prefill() ran: 0 digit planes (+ f16 hand-over / hybrid), 1 the f16 chain, 2 the QB32 chain
     int prefill_qb32_ = -1;   // BITNET_HOST_PREFILL_QB32: -1 not read yet; 1 = the QB32 chain where it applies (opt-in), 0 (default) = quantiser launches
     int prefill_fp6_ = -1;    // BITNET_HOST_PREFILL_FP6: -1 not yet decided, 0 int8 digit planes, 1 the fp6 x fp4 form on resident fp4 images (fp6_flag)

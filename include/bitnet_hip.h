@@ -276,6 +276,12 @@ int bitnet_hip_weights_fp4_image(bitnet_hip_weights_t h, int enable, void *strea
  *                  the consumer adds all rows / 64 entries up (n_stats = rows / 64).
  * bitnet_hip_matmul_f16_supported: rows % 256 == 0, cols % 256 == 0, code map values in -2..2, no scales or f16 32-block scales.
  * bitnet_hip_rows_to_f16_dev: the chain's entry (the embedding rows): xh = f16(gamma * x) (gamma nullable) + stats partial 0. */
+/* f16 hand-over rows carry no row scale: a value beyond +-65504 is clamped -- and COUNTED.  Returns the number of lanes (up to four elements each)
+ * that clamped a value of a live token since the last reset, in any of the chain's writers (bitnet_hip_rows_to_f16_dev, the yh outputs of
+ * bitnet_hip_matmul_f16_dev / _matmul_qb32_dev / FUSE_Y_F16); reset != 0 clears it.  Synchronises the device.  A host that cannot rule such
+ * activations out (outlier channels x gamma beyond the f16 range) checks it behind a prompt and repeats the prompt on the row-scaled forms
+ * (bitnet_hip_matmul_fused_dev), as Decoder::prefill does. */
+unsigned long long bitnet_hip_f16_saturations(int reset);
 int bitnet_hip_matmul_f16_supported(bitnet_hip_weights_t w);
 int bitnet_hip_rows_to_f16_dev(const float *x_dev, const float *gamma_dev, size_t m, size_t cols, void *xh_dev, float *stats_dev, void *stream);
 int bitnet_hip_matmul_f16_dev(bitnet_hip_weights_t w, const void *xh_dev, size_t m, const float *stats_in_dev, size_t n_stats,

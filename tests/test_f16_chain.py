@@ -163,3 +163,56 @@ def test_f16_chain_refuses_what_it_cannot_take(hip, torch_):
     with pytest.raises(Exception, match="does not take the f16 chain"):
         hip.matmul_f16_dev(h, xh, 10, y=y)
     hip.weights_free(h)
+
+
+def test_f16_hand_over_saturation_is_counted_and_the_decoder_falls_back(pkg, hip, oracle, torch_):
+    """the f16 chain stores f16(gamma * x) with no row scale and clamped silently at +-65504.  Now every writer COUNTS a clamp
+    (bitnet_hip_f16_saturations) and Decoder::prefill repeats a prompt that clamped anything on the 4-digit planes (30-bit fixed point behind a
+    per-row power-of-two scale) before it takes the logits.  Op level: an in-range call leaves the counter at zero, an outlier channel raises it.
+    Decoder level: a BitNet32-F16 model whose LAST feed-forward LayerNorm weight has one channel at 2e5 (gamma * x far beyond the f16 range on
+    every token, and silu * up beyond it by orders of magnitude; the attention inputs stay in range -- the prompt attention multiplies f16
+    operands whatever the projections do): the chain's result would be wrong; the decoder reports one fallback and matches the oracle."""
+    import importlib
+
+    synth = importlib.import_module("bitnet-rs_amd.synth")
+    rng = np.random.default_rng(5)
+    m, cols = 200, 512
+    x = rng.normal(0.0, 1.0, (m, cols)).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, cols).astype(np.float32)
+    xh = torch_.zeros(256, cols, dtype=torch_.float16, device="cuda")
+    st = torch_.zeros(2 * 256, device="cuda")
+    hip.f16_saturations(True)
+    hip.rows_to_f16_dev(torch_.from_numpy(x).cuda(), torch_.from_numpy(g).cuda(), m, cols, xh, st)
+    assert hip.f16_saturations(True) == 0
+    g2 = g.copy()
+    g2[17] = 3e5
+    hip.rows_to_f16_dev(torch_.from_numpy(x).cuda(), torch_.from_numpy(g2).cuda(), m, cols, xh, st)
+    n = hip.f16_saturations(True)
+    assert 0 < n <= m and hip.f16_saturations(False) == 0  # one lane per row whose element 17 left the range; reading resets
+    assert np.all(np.abs(xh.cpu().numpy()[:m, 17][np.abs(x[:, 17] * 3e5) > 65504]) == 65504.0)
+    # ---- decoder level
+    cfg = synth.ModelConfig(hidden=512, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, ffn=1024, vocab=2048, max_pos=320, eps=1e-5, rope_theta=10000.0)
+    glob = synth.make_globals(cfg)
+    layers = [synth.make_layer(cfg, l, fmt="i2s", block=32) for l in range(cfg.n_layers)]
+    layers[-1]["ffn_norm"] = layers[-1]["ffn_norm"].copy()
+    layers[-1]["ffn_norm"][33] = 2e5
+    om = oracle.OracleModel(cfg, [dict(w, ternary=32) for w in layers], glob, n_threads=8)
+    T = 256
+    prompt = synth.prompt(T, cfg.vocab)
+    want = None
+    for t in prompt:
+        _, want, _ = om.step(int(t), want_logits=True)
+    om.close()
+    dec = pkg.HostDecoder(cfg)
+    for l, w in enumerate(layers):
+        dec.set_layer_i2s(l, w, 32)
+    dec.set_globals(glob)
+    dec.reset()
+    dec.feed(prompt)
+    dec.prefill(T, with_logits=True, digits=2)
+    assert dec.saturation_fallbacks() == 1 and dec.last_prefill_path() == 0
+    got = dec.last_logits().astype(np.float64)
+    c = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+    assert c >= 0.9999, c
+    assert int(dec.history(T + 1)[T]) == oracle.argmax(want)
+    dec.close()
