@@ -27,6 +27,14 @@
  *
  * There is NO CPU fallback behind any symbol: without a HIP device every compute
  * entry point fails with BITNET_HIP_ERR_GPU.
+ *
+ * ONE SKU.  The launch heuristics -- token-tile and row-tile choices of the tiled matmuls, the
+ * weight-stationary group size, the grid covers, the attention's key splits, the GEMV's workgroup
+ * counts -- are constants tuned for MI355X: 256 CUs in 8 XCDs, 4 MiB of L2 per XCD, 160 KiB of
+ * LDS per CU, 512 registers per SIMD lane.  Results do not depend on them (placement and tiling
+ * change speed only); on another gfx950 part they would want re-tuning (kGemmCUs, the cover
+ * thresholds, gemm_weight_group's 1.5 MiB in kernels_gemm.hip; Decoder::hybrid_applies' 400
+ * workgroups in host/decoder.cpp).  Environment switches that steer them: INTEGRATION.md.
  */
 #ifndef BITNET_HIP_H
 #define BITNET_HIP_H

@@ -32,7 +32,7 @@ def short(name: str) -> str:
 
 
 DOMINANT = ("k_gemv_q<8, 5", "k_gemv_mfma<8, 5")  # the fused gate|up GEMV (RING 5: paired matrix at K = 2560)
-DOMINANT_PREFILL = ("k_gemm_mfma", "k_gemm_f16a")              # prefill passes: the tiled matmul with the largest total time (gate|up)
+DOMINANT_PREFILL = ("k_gemm_mfma", "k_gemm_f16a", "k_gemm_fp6")  # prefill passes: the tiled matmul with the largest total time (gate|up)
 
 
 def newest(pattern_dir: str, suffix: str):
