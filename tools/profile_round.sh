@@ -19,7 +19,7 @@
 #   usage: tools/profile_round.sh <tag> [passes]   passes: any of c2 c3 c4 stream prefill provider (default: all)
 # The program sits directly behind `--`: no env / bash -c hop under rocprofv3.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 shift
 PASSES=${*:-stream prefill c2 c3 c4 provider}   # stream and prefill first: their traffic_*.json (written into profiles/ as each pass ends) are what the bench lines of c2 / c4 quote
 export TMPDIR=/tmp
