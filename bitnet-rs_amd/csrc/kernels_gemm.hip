@@ -65,6 +65,7 @@ struct GemmArgs {
     uint8_t *qb_out = nullptr;         // producer: records of the OUTPUT rows [m_pad][qb_nblk_out][592] (gamma_out * y, the next matmul's K = rows)
     int qb_nblk_out = 0;
     const uint8_t *tiles4 = nullptr;  // k_gemm_fp6<.., RES = 1>: the resident fp4 image [n_tiles][nblk][m 2][64][16] (k_retile_fp4)
+    int bx_off = 0;  // first row block of this launch (the wide gate|up launch is split in two: k_gemm_f16h on the first blocks, k_gemm_f16a on the rest)
     int wgroup = 0;  // > 0: an XCD walks `wgroup` weight row blocks x all token tiles before the next group (gridDim.x % wgroup == 0): gemm_weight_group
 };
 
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
             }
         }
     }
+    bx += p.bx_off;
     const uint8_t *wptr[RT];
     const uint32_t *sptr[RT];
 #pragma unroll
@@ -1288,6 +1290,162 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16a(GemmArgs p, uint32_t lut_h
         return;
     }
     f16_chain_epilogue<RT, TTW, 4, EPI == 2>(p, acc, lds, mu_rs, bx, by, rw, c, g, tid);
+}
+
+// ================================================================================================================================
+// k_gemm_f16h: k_gemm_f16a's arithmetic on a 64-row x 128-TOKEN wave tile (round 5).  The code expansion is a fixed cost per
+// weight and K step (17 VALU per 8 weights: 544 per wave and step against 128 MFMAs at 64 tokens -- the VALU issue port was the unit closest to
+// full, EXPERIMENTS 4.6); at 128 tokens per wave the same expansion feeds 256 MFMAs.  128 f32 accumulators + the 128-token tile only fit with
+// HALF-K LDS steps: a step stages the columns {64 g + 32 hs .. + 31 : g} (four runs of 32: what the MFMAs (m, h), m = 2 hs, 2 hs + 1, take from every
+// lane group) -- 256 bytes per token, 32 KiB per buffer, two buffers, two workgroups per CU as before; the weight / scale tiles are fetched once per
+// 256-column block and used by both halves.  LDS image of a token: 16 units of 16 bytes, unit q = 4 g + k (k = 2 (m - 2 hs) + h) stored at
+// q ^ ((c & 3) | (c & 8)) -- conflict-free for the four 16-lane service groups of ds_read_b128 (brute-forced).  Chain epilogue only (EPI = 1 of
+// k_gemm_f16a), four row tiles per wave.  The launcher pairs it with k_gemm_f16a: 128-token workgroups on as many row blocks as fill whole rounds of
+// the 512 slots, 64-token workgroups on the rest (13824 rows x 4096 tokens: 48 x 32 = 1536 = 3 rounds, then 6 x 64 = 384 half-length ones).
+// LDS-DMA: 64 lanes x 16 B from (scalar base + per-lane byte offset) to LDS bytes [lds_dst, lds_dst + 1024) -- no VGPR staging (kernels_prefill_attn.hip
+// uses the same form).  Invisible to hipcc's vmcnt bookkeeping: the kernel waits for its pieces with an explicit s_waitcnt vmcnt(0) ahead of the barrier
+// that publishes the tile; hipcc's own waits for the weight loads only ever over-wait (loads return in order).
+__device__ __forceinline__ void gdma1k(unsigned lane_off, const void *sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// Register loads as BUFFER loads (SGPR resource descriptor + scalar offset + one 32-bit lane offset): written as pointer arithmetic hipcc folds base + offset
+// into eight 64-bit VGPR pointers and spills them around k_gemm_f16h's 128 accumulators; as buffer loads they cost one VGPR and stay visible to hipcc's
+// vmcnt bookkeeping.  (As inline-asm global loads they were 10 % faster still -- and wrong: hipcc is free to copy an asm output register before the data
+// has landed.)  Matrices below 2 GiB of tiles (the launcher checks).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gbuf_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);  // raw buffer, dword format (gfx94x / gfx950 word 3)
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16h(GemmArgs p, uint32_t lut_hi) {
+    constexpr int RT = 4, TTW = 8, WG_TOK = TTW * 16, ROWB = 256, kBuf = WG_TOK * ROWB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile bases stay in SGPRs)
+    const int c = lane & 15, g = lane >> 4, rw = wave;
+    const int n_tiles = (p.rows + 15) >> 4;
+    const int kp = p.nblk * 256;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {  // one XCD works through consecutive logical ids (k_gemm_mfma explains)
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if ((total & 7) == 0) {
+            const int l = (id & 7) * (total >> 3) + (id >> 3);
+            bx = l % gx;
+            by = l / gx;
+            if (p.wgroup > 0) {
+                const int per = (int)gridDim.y * p.wgroup, grp = l / per, r = l - grp * per;
+                by = r / p.wgroup;
+                bx = grp * p.wgroup + (r - by * p.wgroup);
+            }
+        }
+    }
+    bx += p.bx_off;
+    // wave-uniform bases (SGPR pairs) + 32-bit lane offsets: 128 accumulators leave no room for 64-bit per-lane pointers -- nor for a register-staged
+    // activation tile (32 registers: hipcc spilled 144-228 bytes), so the tile goes global -> LDS by LDS-DMA, one half-K step ahead of its MFMAs
+    const __amdgpu_buffer_rsrc_t rs_w = gbuf_rsrc(p.tiles), rs_s = gbuf_rsrc(FMT == 1 ? (const void *)p.stiles_h : (const void *)p.tiles);
+    int wptr[RT], sptr[RT];  // scalar byte offsets of this wave's row tiles in the code / scale tile arrays
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int t = bx * (4 * RT) + rw * RT + rt;
+        t = t < n_tiles ? t : n_tiles - 1;
+        wptr[rt] = t * p.nblk * 1024;
+        sptr[rt] = t * p.nblk * 256;
+    }
+    const uint32_t woff = (uint32_t)lane * 16u, soff = (uint32_t)(g * 16 + c) * 4u;
+    const uint32_t row_b = (uint32_t)kp * 2u;                                                                    // bytes of a token's f16 row
+    const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)(by * WG_TOK + 32 * wave) * row_b;  // uniform: this wave stages tokens 32 w .. 32 w + 31
+    // A half-step's tile is 32 pieces of 1 KiB (4 tokens x 16 units); wave w moves pieces 8 w .. 8 w + 7.  Lane l of piece i lands at slot (token 4 i + (l >> 4),
+    // position l & 15): it fetches the unit that belongs there, q = (l & 15) ^ col_swz(token & 15) = columns 64 (q / 4) + 32 hs + 8 (q % 4) of the token's row.
+    // token & 15 = 4 (i & 3) + (l >> 4): four lane-offset patterns; pieces i and i + 4 differ by 16 tokens (a scalar).
+    uint32_t dsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tl = 4 * i + (lane >> 4), q = (lane & 15) ^ col_swz(tl);
+        dsrc[i] = (uint32_t)tl * row_b + (uint32_t)((q >> 2) * 128 + (q & 3) * 16);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    auto stage = [&](int s, int buf) {  // half-step s (block s / 2, half s % 2) -> buffer buf
+        const uint8_t *src = abase + (size_t)(s >> 1) * 512 + (size_t)(s & 1) * 64;
+        const unsigned dst = lds0 + (unsigned)buf * kBuf + (unsigned)(8 * wave) * 1024u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gdma1k(dsrc[i & 3], src + (size_t)(i >> 2) * 16 * row_b, dst + 1024u * i);
+    };
+    int boff[4];  // this lane's unit of MFMA k = 2 (m - 2 hs) + h
+#pragma unroll
+    for (int k = 0; k < 4; ++k) boff[k] = c * ROWB + (((4 * g + k) ^ col_swz(c)) * 16);
+    ChainLnStats<WG_TOK, 4> lnst;
+    const bool ln_in = p.stats_in != nullptr;
+    if (ln_in) lnst.issue(p, by, tid);
+    gv4u wn[RT];
+    uint32_t sn[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wn[rt] = __builtin_bit_cast(gv4u, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, wptr[rt], 0)), sn[rt] = 0;
+    if (FMT == 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) sn[rt] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, sptr[rt], 0);
+    }
+    const int n_steps = 2 * p.nblk;
+    stage(0, 0);
+    float2 *mu_rs = reinterpret_cast<float2 *>(lds + 2 * kBuf);
+    double *ln_red = reinterpret_cast<double *>(lds + 2 * kBuf + WG_TOK * 8);
+    if (ln_in) lnst.sum(p, ln_red, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ln_in) lnst.final(p, ln_red, mu_rs, tid);
+    gv4f acc[RT][TTW];  // (declared behind the statistics' twenty registers: with both live the prologue spilled)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        // this block's weights / scales become current; the next block's are requested
+        gv4u wc[RT];
+        uint32_t sc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) wc[rt] = wn[rt], sc[rt] = sn[rt];
+        {
+            const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wn[rt] = __builtin_bit_cast(gv4u, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, wptr[rt] + n1 * 1024, 0));
+            if (FMT == 1) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) sn[rt] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, sptr[rt] + n1 * 256, 0);
+            }
+        }
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {  // (compile-time after unrolling: the half tile of step s = 2 blk + hs sits in buffer hs)
+            const int s = 2 * blk + hs;
+            const uint8_t *bcur = lds + hs * kBuf;
+            if (s + 1 < n_steps) stage(s + 1, hs ^ 1);  // (every wave is past the barrier that ended step s - 1: nobody reads that buffer)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    gh8 a[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        // dword m = 2 hs + mm of the lane's 16 bytes; (s, s) of its 32-block 2 g + hs: low / high half of the scale dword
+                        const uint32_t wd = hs == 0 ? (mm == 0 ? wc[rt].x : wc[rt].y) : (mm == 0 ? wc[rt].z : wc[rt].w);
+                        const gh2 s2v = __builtin_bit_cast(gh2, __builtin_amdgcn_perm(0u, sc[rt], hs ? 0x03020302u : 0x01000100u));
+                        a[rt] = expand8_f16<FMT>(wd, h, lut_hi, s2v);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < TTW; ++ct) {
+                        const gh8 b = *reinterpret_cast<const gh8 *>(bcur + ct * 16 * ROWB + boff[2 * mm + h]);
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b, acc[rt][ct], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next half tile have landed
+            __syncthreads();
+        }
+    }
+    f16_chain_epilogue<RT, TTW, 4>(p, acc, lds, mu_rs, bx, by, rw, c, g, tid);
 }
 
 // ================================================================================================================================
@@ -1612,7 +1770,7 @@ static bool gemm_five_tiles(size_t rows, size_t m_pad) {
 // row blocks), 752 -> 255 MB (BitNet32-F16); the 2560-row launches have few row blocks and wide activation bands and get WORSE (117 -> 188 MB),
 // so only launches of at least 24 row blocks take it.  Time: neutral (the re-reads were never what the K step waits for); results: identical.
 // BITNET_HIP_GEMM_WGROUP: -1 automatic (default), 0 off, n a fixed group.
-static int gemm_weight_group(size_t gx, size_t row_block_rows, size_t cols, bool f16_scales) {
+static int gemm_weight_group(size_t gx, size_t row_block_rows, size_t cols, bool f16_scales, size_t budget = (size_t)3 << 19) {
     static const int mode = [] { const char *e = getenv("BITNET_HIP_GEMM_WGROUP"); return e ? atoi(e) : -1; }();
     if (mode == 0 || gx < 2) return 0;
     if (mode > 0) return gx % (size_t)mode == 0 ? mode : 0;
@@ -1620,9 +1778,14 @@ static int gemm_weight_group(size_t gx, size_t row_block_rows, size_t cols, bool
     const size_t block_bytes = row_block_rows * cols / 4 + (f16_scales ? row_block_rows * cols / 16 : 0);
     int best = 0;
     for (size_t g = 2; g <= gx; ++g)
-        if (gx % g == 0 && g * block_bytes <= (size_t)3 << 19) best = (int)g;  // <= 1.5 MiB per group
+        if (gx % g == 0 && g * block_bytes <= budget) best = (int)g;  // <= 1.5 MiB per group (2 MiB of a resident fp4 image: kFp4GroupBudget)
     return best;
 }
+// The resident fp4 image is twice the bytes per row block: under the 1.5 MiB rule gate|up's groups shrink from 9 row blocks to 3 and every group pass
+// re-reads the 23.6 MB of fp6 planes -- rocprofv3 --pmc FETCH_SIZE per gate|up launch (fabric requests: the Infinity Cache serves them), groups of
+// 0 / 2 / 3 / 6 / 9 / 18 / 27 row blocks: 1179 / 713 / 541 / 372 / 420 / 710 / 1001 MB (algorithmic: 41 MB; eight L2s each need the planes once per
+// group they walk); prompt 18.80 (3) / 18.73 (6) / 18.64 (9) ms same box.  2 MiB admits 6.
+constexpr size_t kFp4GroupBudget = (size_t)2 << 20;
 static int gemm_ttw(int ndig, int ws) { return ws >= 2 ? (ndig <= 3 ? 2 : 1) : (ndig == 2 && !ws) ? 4 : 2; }
 
 // 32-block scales that are f16 values go through the K = 32 path and its f16 scale tiles; the others read row-major f32 scales
@@ -1821,7 +1984,7 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 6, rt5 ? 80 : 64, res ? 1 : 0};
     GemmArgs aw = a;
-    aw.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);  // (the image is twice the bytes per row block)
+    aw.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false, res ? kFp4GroupBudget : (size_t)3 << 19);  // (the image is twice the bytes per row block)
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, aw, lut_fp4(w.lut));
     return hipGetLastError();
 }
@@ -1898,6 +2061,42 @@ hipError_t launch_gemm_f16_chain(const Weights &w, const GemmF16Io &io, size_t m
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, fmt1 ? 4 : 5, rt5 ? 80 : 64};
     const size_t lds = (size_t)2 * ttw * 16 * 512 + (size_t)ttw * 16 * 8 + 4096;  // two tile buffers + the tokens' (mean, 1 / denom) + the statistics scratch
+    // Wide launches (gate|up: 54 row blocks): 128-token workgroups (k_gemm_f16h: half the code expansion per MFMA) on as many row blocks as fill WHOLE rounds
+    // of the 512 slots, this kernel's 64-token workgroups on the rest -- 13824 rows x 4096 tokens: 48 x 32 = 1536 workgroups = 3 rounds, then 6 x 64 = 384
+    // half-length ones (as one 128-token grid it would be 3.375 rounds: the 16 % idle tail would cost more than the expansion saves).  Same arithmetic per
+    // output element whichever kernel computes it (k-order, f32 accumulation): bit-identical to the one-kernel launch.  BITNET_HIP_GEMM_F16H=0: off.
+    static const int f16h_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_F16H"); return e ? atoi(e) : 1; }();
+    const size_t slots = 2 * kGemmCUs;
+    if (f16h_mode && ttw == 4 && !rt5 && !io.qb_out && m_pad % 128 == 0 && w.rows * w.cols / 4 < ((size_t)1 << 31)) {
+        const size_t t128 = m_pad / 128;
+        size_t n_a = (gx0 * t128 / slots) * slots / t128;  // row blocks whose 128-token workgroups fill whole rounds
+        // a launch whose 128-token workgroups fit ONE round that is at least three quarters full (q|k|v: 15 x 32 = 480 of 512 slots, against 960 = 1.9 rounds of
+        // 64-token ones: a 128-token workgroup takes 1.85 x a 64-token one) goes to k_gemm_f16h whole
+        if (gx0 * t128 <= slots && 4 * gx0 * t128 >= 3 * slots) n_a = gx0;
+        if (gx0 < 24 && n_a != gx0) n_a = 0;
+        if (n_a >= gx0 / 2 && n_a > 0) {
+            void (*hk)(GemmArgs, uint32_t) = fmt1 ? k_gemm_f16h<1> : k_gemm_f16h<0>;
+            {
+                static std::mutex h_mu;
+                static std::unordered_set<const void *> h_raised;
+                std::lock_guard<std::mutex> lk(h_mu);
+                if (!h_raised.count((const void *)hk)) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return e;
+                    h_raised.insert((const void *)hk);
+                }
+            }
+            GemmArgs aa = a;
+            aa.wgroup = gemm_weight_group(n_a, 256, w.cols, fmt1);
+            hipLaunchKernelGGL(hk, dim3((unsigned)n_a, (unsigned)t128), dim3(256), (size_t)2 * 128 * 256 + 128 * 8 + 4096, stream, aa, lut_f16_hi(w.lut));
+            g_last_gemm_tile = GemmTileChoice{2, 128, 4, fmt1 ? 4 : 5, 64};
+            if (n_a == gx0) return hipGetLastError();
+            a.bx_off = (int)n_a;
+            a.wgroup = 0;
+            hipLaunchKernelGGL(fk, dim3((unsigned)(gx0 - n_a), (unsigned)(m_pad / 64)), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
+            return hipGetLastError();
+        }
+    }
     a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, w.cols, fmt1);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), lds, stream, a, lut_f16_hi(w.lut));
     return hipGetLastError();
@@ -1964,7 +2163,7 @@ hipError_t launch_gemm_qb32(const Weights &w, const GemmF16Io &io, size_t m, hip
         }
     }
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 8, rt5 ? 80 : 64, res ? 1 : 0};  // scale_mode 8: the fp6 form on QB32 rows
-    a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false);
+    a.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false, res ? kFp4GroupBudget : (size_t)3 << 19);
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * (576 + 8) + (size_t)ttw * 16 * 8 + 4096, stream, a, lut_fp4(w.lut));
     return hipGetLastError();
 }

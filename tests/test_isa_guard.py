@@ -114,13 +114,24 @@ def test_resources_of_the_benchmarked_instantiations(isa):
 
 # the one instantiation hipcc 7.2 spills: 4 digits x 256-element block scales on the 8-wave tile (128 int32 + 64 f32 accumulators);
 # reached only by digits = 4 on a 256-block-scaled matrix, never by bench.py or the decoder's default (2 digits)
-KNOWN_SCRATCH = {"_ZN10bitnet_hip11k_gemm_mfmaILi4ELi2ELi1ELi1ELi2EEEvNS_8GemmArgsE"}
+# ... and k_gemm_f16h<1> (round 5: 64 x 128 wave tile of the BitNet32-F16 gate|up launch, 128 accumulators): 76 bytes, ONE scratch load per half-K step
+# (128 MFMAs) in the loop, the rest in the prologue / epilogue -- bounded below so that it cannot grow unnoticed
+GEMMF16H = "_ZN10bitnet_hip11k_gemm_f16hILi1EEEvNS_8GemmArgsEj"
+KNOWN_SCRATCH = {"_ZN10bitnet_hip11k_gemm_mfmaILi4ELi2ELi1ELi1ELi2EEEvNS_8GemmArgsE", GEMMF16H}
 
 
 def test_no_scratch_anywhere_else_in_the_prefill_sources(isa):
     for src, (lines, usage) in isa.items():
         for name, u in usage.items():
             assert u["ScratchSize"] == 0 or name in KNOWN_SCRATCH, (src, name, u)
+    lines, usage = isa["kernels_gemm.hip"]
+    assert usage[GEMMF16H]["ScratchSize"] <= 96 and usage[GEMMF16H]["Occupancy"] >= 2, usage[GEMMF16H]
+    body = body_of(lines, GEMMF16H)
+    for a, b in inner_loops(body):  # the K loop (both half steps unrolled): at most one scratch access per half step, 128 MFMAs each, no stores
+        ins = [t for _, _, t in classify(body[a:b + 1])]
+        if sum(t.startswith("v_mfma") for t in ins) >= 128:
+            assert sum(t.startswith("scratch_") for t in ins) <= 2, [t for t in ins if t.startswith("scratch_")]
+            assert not any(t.startswith(("global_store", "buffer_store")) for t in ins)
     for name in (ATTN, GEMM64, GEMM32, GEMMF16, GEMMF16_R5, GEMMF16_R5_QK, GEMMFP6):
         src = "kernels_prefill_attn.hip" if name == ATTN else "kernels_gemm.hip"
         assert not any(re.match(r"\s*scratch_", l) for l in body_of(isa[src][0], name)), name
