@@ -378,9 +378,21 @@ def prefill_roofline(hip, dec, cfg, n_tokens: int, digits: int, fmt_qk256: bool,
     torch.cuda.synchronize()
 
     form = {"flags": 1}
+    chain = (not fmt_qk256) and digits == 2 and hip.matmul_f16_supported(gateup) and os.environ.get("BITNET_HOST_PREFILL_CHAIN", "-1") != "0"
+    if chain:
+        # BitNet32-F16: the launch the prompt forward ISSUES -- the f16 chain's gate|up (f16 rows in, LayerNorm after the product from the statistics partials,
+        # silu * up as f16 rows out; k_gemm_f16h on 48 row blocks + k_gemm_f16a on 6 at 4096 tokens: two kernels, one call), no quantiser launch
+        m_pad = -(-n_tokens // 64) * 64
+        xh = torch.zeros(m_pad, K, dtype=torch.float16, device="cuda")
+        st = torch.zeros(m_pad * 2, device="cuda")
+        hip.rows_to_f16_dev(x, ffn_norm, n_tokens, K, xh, st, stream=stream.cuda_stream)
+        yh = torch.empty(m_pad, F, dtype=torch.float16, device="cuda")
 
-    def launch():
-        hip.matmul_fused_dev(gateup, x, y, n_tokens, ws, wsb, ln_gamma=ffn_norm, ln_eps=cfg.eps, flags=form["flags"], digits=digits, stream=stream.cuda_stream)
+        def launch():
+            hip.matmul_f16_dev(gateup, xh, n_tokens, stats_in=st, n_stats=1, ln_gamma=ffn_norm, ln_eps=cfg.eps, flags=1, yh=yh, stream=stream.cuda_stream)
+    else:
+        def launch():
+            hip.matmul_fused_dev(gateup, x, y, n_tokens, ws, wsb, ln_gamma=ffn_norm, ln_eps=cfg.eps, flags=form["flags"], digits=digits, stream=stream.cuda_stream)
 
     if fmt_qk256 and digits == 2 and os.environ.get("BITNET_HOST_PREFILL_FP6", "1") != "0":
         form["flags"] = 1 | 16  # BITNET_HIP_FUSE_FP6_DIGITS: the form the decoder's prompt forward takes for q|k|v and gate|up of an unscaled model (resident fp4 image)
@@ -401,7 +413,8 @@ def prefill_roofline(hip, dec, cfg, n_tokens: int, digits: int, fmt_qk256: bool,
     peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_FP6_PEAK_TOPS if fp6 else MFMA_I8_PEAK_TOPS
     alg = 2.0 * n_tokens * 2 * F * K / us / 1e6
     return {"bound": "mfma-f16" if f16 else "mfma-f8f6f4 (fp4 x fp6)" if fp6 else "mfma-i8",
-            "kernel": ("k_gemm_f16a" if f16 else "k_gemm_fp6 (resident fp4 weights)" if fp6 else "k_gemm_mfma") + " (+ its row quantiser): LayerNorm -> gate|up -> silu*mul",
+            "kernel": ("k_gemm_f16h + k_gemm_f16a (f16 chain: f16 rows in, no quantiser): LayerNorm after the product -> gate|up -> silu*mul" if chain else
+                       ("k_gemm_f16a" if f16 else "k_gemm_fp6 (resident fp4 weights)" if fp6 else "k_gemm_mfma") + " (+ its row quantiser): LayerNorm -> gate|up -> silu*mul"),
             "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s" if f16 else "TOP/s", "frac": round(achieved / peak, 4),
             "counts": "2 m n k" if f16 else "matrix-core operations issued (2 m n k x 3 base-32 digits)" if fp6 else "matrix-core operations issued (2 m n k x digits)",
             "algorithmic": {"TFLOPs": round(alg, 1), "frac_of_f16_peak": round(alg / MFMA_F16_PEAK_TFLOPS, 4)},

@@ -238,3 +238,77 @@ def test_f16_hand_over_saturation_is_counted_and_the_decoder_falls_back(pkg, hip
     assert c >= 0.9999, c
     assert int(dec.history(T + 1)[T]) == oracle.argmax(want)
     dec.close()
+
+
+_F16H_HASH_SCRIPT = r"""
+import hashlib, importlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests")
+pkg = importlib.import_module("bitnet-rs_amd"); synth = importlib.import_module("bitnet-rs_amd.synth")
+hip = pkg.load(); hip.init(0)
+import test_f16_chain as T
+print("HASH", T.f16h_case(hip, torch, {fmt!r}, {kind!r})[0])
+"""
+
+
+def f16h_case(hip, torch_, fmt, kind):
+    """The wide chain launches of a 4096-token prompt at the 2B-4T widths: kind 'gateup' (13824 x 2560, LayerNorm after the product, silu * up -> f16
+    rows) or 'qkv' (3840 x 2560, LayerNorm -> f32 rows).  -> (sha256 of the output bytes, outputs, the pieces a checker needs)."""
+    import hashlib
+
+    rng = np.random.default_rng(123)
+    K, m = 2560, 4096
+    N = 6912 if kind == "gateup" else 1920
+    ha, wa = make_matrix(hip, rng, fmt, N, K)
+    hb, wb = make_matrix(hip, rng, fmt, N, K)
+    x = rng.normal(0.15, 1.0, (m, K)).astype(np.float32)
+    g = (rng.uniform(0.5, 1.5, K) / (80 if fmt == "qk256" else 4)).astype(np.float32)
+    gd = torch_.from_numpy(g).cuda()
+    xh = torch_.zeros(m, K, dtype=torch_.float16, device="cuda")
+    st = torch_.zeros(1, m, 2, device="cuda")
+    hip.rows_to_f16_dev(torch_.from_numpy(x).cuda(), gd, m, K, xh, st)
+    h = hip.weights_concat([ha, hb], interleave16=(kind == "gateup"))
+    hip.weights_bind_ln(h, gd)
+    if kind == "gateup":
+        out = torch_.full((m, N), float("nan"), dtype=torch_.float16, device="cuda")
+        hip.matmul_f16_dev(h, xh, m, stats_in=st, n_stats=1, ln_gamma=gd, ln_eps=1e-5, flags=1, yh=out)
+    else:
+        out = torch_.full((m, 2 * N), float("nan"), device="cuda")
+        hip.matmul_f16_dev(h, xh, m, stats_in=st, n_stats=1, ln_gamma=gd, ln_eps=1e-5, y=out)
+    torch_.cuda.synchronize()
+    tile = dict(hip.matmul_last_tile())
+    o = out.cpu().numpy()
+    for hh in (ha, hb, h):
+        hip.weights_free(hh)
+    return hashlib.sha256(o.tobytes()).hexdigest(), o, (x, g, wa, wb, tile)
+
+
+@pytest.mark.parametrize("fmt", ["i2s", "qk256"])
+@pytest.mark.parametrize("kind", ["gateup", "qkv"])
+def test_f16h_wide_tile_instances_match_oracle_and_the_64_token_kernel(hip, oracle, torch_, fmt, kind):
+    """k_gemm_f16h (round 5): the 64-row x 128-token wave tile the f16 chain's wide launches take at 4096 tokens -- gate|up split 48 + 6 row blocks
+    (the six on k_gemm_f16a), q|k|v whole (480 workgroups: one round).  Tile asserted; sampled rows against the oracle's LayerNorm + product
+    (+ silu * up); and the WHOLE output bit-identical to the launch with BITNET_HIP_GEMM_F16H=0 (k_gemm_f16a alone: same k-order, same f32
+    accumulation per output element) -- the switch is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    h1, out, (x, g, wa, wb, tile) = f16h_case(hip, torch_, fmt, kind)
+    assert tile["wave_tokens"] == 128 and tile["digits"] == 2 and tile["scale_mode"] == (4 if fmt == "i2s" else 5), tile
+    assert np.isfinite(out.astype(np.float64)).all()
+    rng = np.random.default_rng(9)
+    for i in np.unique(np.r_[0, 4095, rng.integers(0, 4096, 6)]):
+        xn = oracle.layernorm(x[i], g, 1e-5).astype(np.float64)
+        a, b = xn @ wa.T, xn @ wb.T
+        want = a / (1 + np.exp(-a)) * b if kind == "gateup" else np.concatenate([a, b])
+        got = out[i].astype(np.float64)
+        assert cosine(got, want) >= 0.99999, int(i)
+        assert np.max(np.abs(got - want)) <= 2.5e-3 * np.max(np.abs(want)), int(i)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _F16H_HASH_SCRIPT.format(root=root, fmt=fmt, kind=kind)], env=dict(os.environ, BITNET_HIP_GEMM_F16H="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    h0 = [l.split()[1] for l in p.stdout.splitlines() if l.startswith("HASH ")][0]
+    assert h0 == h1, "k_gemm_f16h's outputs differ from k_gemm_f16a's"
