@@ -246,6 +246,160 @@ __global__ __launch_bounds__(256) void k_quant_rows(QuantArgs p) {
     }
 }
 
+// f64 sum over the wave on the VALU: DPP steps inside a row of 16 lanes (quad_perm, row_half_mirror, row_mirror: each lane adds a partner
+// that holds the other half of its group), v_permlane16_swap / v_permlane32_swap across rows -- no ds_bpermute round trips.  Every
+// lane ends with the same value (a fixed order of additions).
+template <int CTRL>
+__device__ __forceinline__ double qdpp_d(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double qswap_d(double v, bool rows32) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t l = (uint32_t)u, h = (uint32_t)(u >> 32);
+    // with both operands the same register the swap leaves (own, partner) in some order in the two results: their sum is what is wanted
+    const auto a = rows32 ? __builtin_amdgcn_permlane32_swap(l, l, false, false) : __builtin_amdgcn_permlane16_swap(l, l, false, false);
+    const auto b = rows32 ? __builtin_amdgcn_permlane32_swap(h, h, false, false) : __builtin_amdgcn_permlane16_swap(h, h, false, false);
+    return __builtin_bit_cast(double, ((uint64_t)b[0] << 32) | a[0]) + __builtin_bit_cast(double, ((uint64_t)b[1] << 32) | a[1]);
+}
+__device__ __forceinline__ double qwave_sum_d_valu(double v) {
+    v += qdpp_d<0xB1>(v);
+    v += qdpp_d<0x4E>(v);
+    v += qdpp_d<0x141>(v);
+    v += qdpp_d<0x140>(v);
+    v = qswap_d(v, false);
+    return qswap_d(v, true);
+}
+
+// ---- the 2-digit quantiser for rows of up to 2560 columns (round 5): ONE WAVE PER ROW ----------------
+// k_quant_rows<2, 3, FP6> is instruction bound, not memory bound (ISA count: ~2,600 wave-instructions per 2560-column row -- an IEEE
+// division per element for the LayerNorm, f64 butterflies over ds_bpermute, four workgroup barriers, the fp6 packing on 80 of 256
+// threads -- = 20 us for 4096 rows where the bytes need 12).  Here a wave owns a row (ten float4 per lane, all in flight at once; no
+// barrier before the row's integers exist), the LayerNorm folds into the quantiser's own multiplier:
+//     q = rint(((x - mean) * gamma) * k),  k = 2^(S - E) / denom,  E = exponent of max |(x - mean) * gamma| / denom
+// (one division per ROW; the int8 and the fp6 forms call the same code, so they still carry the same integer bit for bit), and the four
+// rows of a workgroup pack their 4 x 80 units on all 256 threads.  Same layouts as k_quant_rows.
+template <int FP6>
+__global__ __launch_bounds__(256, 4) void k_quant_rows_w(QuantArgs p) {
+    constexpr int S = 13, NV = 10;
+    extern __shared__ __attribute__((aligned(16))) uint8_t qrow_all[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = (int)blockIdx.x * 4 + wave;
+    const int nvec = p.cols >> 2, kvec = p.kp >> 2, n_units = p.kp >> 5, nblk = p.kp >> 8;
+    const bool live = row < p.m;
+    const int rr = live ? row : p.m - 1;
+    float4 v[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i, ci = idx < nvec ? idx : nvec - 1;
+        if (p.x_f16) {  // (uniform)
+            typedef _Float16 qh4 __attribute__((ext_vector_type(4)));
+            const qh4 hv = *reinterpret_cast<const qh4 *>(reinterpret_cast<const _Float16 *>(p.x) + (size_t)rr * p.cols + 4 * ci);
+            v[i] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {
+            v[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)rr * p.cols + 4 * ci);
+        }
+        gm[i] = p.ln_gamma ? *reinterpret_cast<const float4 *>(p.ln_gamma + 4 * ci) : float4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i >= nvec || !live) v[i] = float4{0.f, 0.f, 0.f, 0.f}, gm[i] = float4{0.f, 0.f, 0.f, 0.f};
+    float denom = 1.0f;  // (1 / denom is never formed: denom divides the row's maximum and the multiplier, once each)
+    if (p.ln_gamma) {
+        // LayerNorm without bias, with mean subtraction (T:67-100): sums in f64 over the exact f32 values
+        // (two independent chains each, one add / one fma per element: the f64 pipe runs at half rate and is this kernel's busiest unit)
+        double s1a = 0.0, s1b = 0.0, s2a = 0.0, s2b = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double a = v[i].x, b = v[i].y, c = v[i].z, d = v[i].w;
+            s1a += a, s1b += b, s1a += c, s1b += d;
+            s2a = __builtin_fma(a, a, s2a), s2b = __builtin_fma(b, b, s2b), s2a = __builtin_fma(c, c, s2a), s2b = __builtin_fma(d, d, s2b);
+        }
+        double s1 = qwave_sum_d_valu(s1a + s1b);
+        double s2 = qwave_sum_d_valu(s2a + s2b);
+        const double mean_d = s1 / (double)p.cols, var_d = s2 / (double)p.cols - mean_d * mean_d;
+        const float mean = (float)mean_d;
+        denom = sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x = (v[i].x - mean) * gm[i].x;
+            v[i].y = (v[i].y - mean) * gm[i].y;
+            v[i].z = (v[i].z - mean) * gm[i].z;
+            v[i].w = (v[i].w - mean) * gm[i].w;
+        }
+    }
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    am = qwave_max(am) / denom;
+    int be = (int)((__float_as_uint(am) >> 23) & 0xffu);
+    be = be < 32 ? 32 : be;
+    const float sc = __uint_as_float((uint32_t)(254 + S - be) << 23) / denom;  // 2^(S - E) / denom
+    const float inv_s = __uint_as_float((uint32_t)(be - S) << 23);             // 2^(E - S)
+    if (lane == 0) p.inv_scale[row] = live ? inv_s : 0.0f;
+    if (!FP6) {
+        int8_t *base = p.planes + ((size_t)(row >> 4) * 2 * 16 + (row & 15)) * p.kp;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx >= kvec) continue;
+            // balanced base-256 digits: bytes of (q + 0x80) ^ 0x80, then a 4 x 4 byte transpose to one dword per digit plane (k_quant_rows)
+            constexpr uint32_t B = 0x00000080u;
+            const uint32_t e0 = ((uint32_t)__float2int_rn(v[i].x * sc) + B) ^ B, e1 = ((uint32_t)__float2int_rn(v[i].y * sc) + B) ^ B;
+            const uint32_t e2 = ((uint32_t)__float2int_rn(v[i].z * sc) + B) ^ B, e3 = ((uint32_t)__float2int_rn(v[i].w * sc) + B) ^ B;
+            const uint32_t lo01 = __builtin_amdgcn_perm(e1, e0, 0x05010400u), lo23 = __builtin_amdgcn_perm(e3, e2, 0x05010400u);
+            *reinterpret_cast<uint32_t *>(base + 4 * idx) = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+            *reinterpret_cast<uint32_t *>(base + (size_t)16 * p.kp + 4 * idx) = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+        }
+        return;
+    }
+    // the row's integers go through LDS as int16 (|q| <= 2^14), so that ONE work item owns the 32 columns of an MFMA operand: a unit's 64
+    // bytes sit in 80 (five 16-byte granules per unit: the sixteen lanes of a ds_read_b128 service group touch sixteen different granules).
+    // 25.6 KB per workgroup: all 1024 workgroups of a 4096-row launch are resident at once (the f32 image + a staged copy of the packed rows
+    // took 69 KB: two workgroups per CU, two rounds: 16.7 us; the packed units now leave straight from the registers)
+    const int row_q = n_units * 80;  // bytes per row
+    uint8_t *qall = reinterpret_cast<uint8_t *>(qrow_all), *qrow = qall + (size_t)wave * row_q;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx >= kvec) continue;
+        const auto a = __builtin_amdgcn_cvt_pk_i16(__float2int_rn(v[i].x * sc), __float2int_rn(v[i].y * sc));
+        const auto b = __builtin_amdgcn_cvt_pk_i16(__float2int_rn(v[i].z * sc), __float2int_rn(v[i].w * sc));
+        *reinterpret_cast<uint2 *>(qrow + (idx >> 3) * 80 + (idx & 7) * 8) = uint2{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+    }
+    __syncthreads();
+    typedef float qv16f __attribute__((ext_vector_type(16)));
+    typedef unsigned qv6u __attribute__((ext_vector_type(6)));
+    const size_t row_b = (size_t)nblk * 576;  // packed bytes per row
+    for (int j = tid; j < 4 * n_units; j += 256) {
+        const int r = j / n_units, u = j - r * n_units;
+        const uint8_t *qr = qall + (size_t)r * row_q + u * 80;
+        qv16f lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // 16-byte granule k: columns 8 k .. 8 k + 7 of the unit
+            const uint4 w = *reinterpret_cast<const uint4 *>(qr + 16 * k);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (float)(int16_t)(ws[e >> 1] >> (16 * (e & 1)));
+                const float r1 = __builtin_rintf(x * 0.03125f), d0 = __builtin_fmaf(r1, -32.0f, x);
+                const float r2 = __builtin_rintf(r1 * 0.03125f), d1 = __builtin_fmaf(r2, -32.0f, r1);
+                const int ix = 4 * k + (e & 3);  // k-slot 8 k + 2 (e & 3) + (e >> 2): first operand = columns 8 k + 0 .. 3, second = 8 k + 4 .. 7
+                if (e & 4) hi[0][ix] = d0, hi[1][ix] = d1, hi[2][ix] = r2;
+                else lo[0][ix] = d0, lo[1][ix] = d1, lo[2][ix] = r2;
+            }
+        }
+        uint8_t *ob = reinterpret_cast<uint8_t *>(p.planes) + ((size_t)blockIdx.x * 4 + r) * row_b + (size_t)(u >> 3) * 576 + ((u >> 1) & 3) * 144 + (u & 1) * 24;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const qv6u c6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo[d], hi[d], 8.0f);
+            uint2 *o = reinterpret_cast<uint2 *>(ob + d * 48);
+            o[0] = uint2{c6[0], c6[1]}, o[1] = uint2{c6[2], c6[3]}, o[2] = uint2{c6[4], c6[5]};
+        }
+    }
+}
+
 __device__ __forceinline__ v4i gdecode16(uint32_t w, uint32_t lut) {
     v4i a;
     a[0] = (int)__builtin_amdgcn_perm(0u, lut, w & 0x03030303u);
@@ -1806,11 +1960,27 @@ size_t gemm_workspace_bytes(size_t m, size_t cols, int ndig) {
     return m_pad * plane_bytes + div_ceil(m_pad * sizeof(float), 256) * 256 + 256;
 }
 
+// 2 digits, rows of up to 2560 columns: the wave-per-row quantiser (both digit forms: the int8 planes and the fp6 form stay bit-identical)
+static bool quant_rows_w_applies(const QuantArgs &q) {
+    static const int mode = [] { const char *e = getenv("BITNET_HIP_QUANT_W"); return e ? atoi(e) : 1; }();
+    return mode != 0 && q.kp <= 2560 && q.m_pad % 4 == 0;
+}
+static void launch_quant_rows_w(const QuantArgs &q, bool fp6, hipStream_t stream) {
+    if (fp6) {
+        static std::once_flag raised;
+        std::call_once(raised, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quant_rows_w<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024); });
+        hipLaunchKernelGGL(k_quant_rows_w<1>, dim3(q.m_pad / 4), dim3(256), (size_t)4 * (size_t)(q.kp / 32) * 80, stream, q);
+    } else {
+        hipLaunchKernelGGL(k_quant_rows_w<0>, dim3(q.m_pad / 4), dim3(256), 0, stream, q);
+    }
+}
+
 template <int NDIG, int TTW>
 static hipError_t launch_gemm_t(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
     const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<NDIG, 3> : k_quant_rows<NDIG, 8>;
-    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
+    if (NDIG == 2 && quant_rows_w_applies(q)) launch_quant_rows_w(q, false, stream);
+    else hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), 0, stream, q);
     constexpr int TTWS = 2;  // scaled variant: narrower token tile (f32 accumulators take the registers)
     const bool k32 = a.stiles_h != nullptr;
     const bool bs32 = (a.wscale && w.block_size == 32) || k32;  // 32-block scales: one token tile per wave (registers)
@@ -1962,7 +2132,8 @@ bool gemm_takes_fp6(const Weights &w, const GemvFusion &fu, int ndig) {
 static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const GemmArgs &a, hipStream_t stream) {
     const int nv = (int)div_ceil((size_t)q.kp / 4, 256);
     void (*qk)(QuantArgs) = nv <= 3 ? k_quant_rows<2, 3, 1> : k_quant_rows<2, 8, 1>;
-    hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), (size_t)(q.kp / 32) * 144 + (size_t)(q.kp / 256) * 576, stream, q);  // LDS: the row's integers (144 bytes per 32 columns) + its packed image
+    if (quant_rows_w_applies(q)) launch_quant_rows_w(q, true, stream);
+    else hipLaunchKernelGGL(qk, dim3(q.m_pad), dim3(256), (size_t)(q.kp / 32) * 144 + (size_t)(q.kp / 256) * 576, stream, q);  // LDS: the row's integers (144 bytes per 32 columns) + its packed image
     size_t gx0 = div_ceil(div_ceil(w.rows, 16), 16);
     static const size_t cover = [] { const char *e = getenv("BITNET_HIP_FP6_COVER"); return e ? (size_t)atoi(e) : 2 * kGemmCUs; }();  // (developer sweep of the token tile)
     int ttw = gemm_token_tiles(gx0, q.m_pad, false, cover);

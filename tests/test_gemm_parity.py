@@ -413,3 +413,52 @@ def test_fp6_form_silu_handover_and_refusals(hip, torch_):
         hip.matmul_fused_dev(hs, xd, ya, m, ws, wsb, digits=2, flags=FP6_DIGITS)
     for h in (ha, hb, hg, hs):
         hip.weights_free(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [2560, 1024, 1100])
+def test_wave_per_row_quantiser_carries_the_documented_integer(hip, torch_, K):
+    """k_quant_rows_w (round 5: 2 digits, rows of up to 2560 columns, both digit forms): q = rint(((x - mean) * gamma) * k) with
+    k = 2^(13 - E) / denom and E the exponent of max |(x - mean) * gamma| / denom -- restated here in numpy f32 / f64, operation for
+    operation.  Every product and partial sum behind the quantiser is an exact integer, so the launch must give f32(W q) * 2^(E - 13)
+    EXACTLY wherever the model's q is the kernel's; the f64 statistics may be added up in another order (a mean one f32 ulp off moves a
+    handful of q by one unit), hence: at least 99 % of the outputs bit-equal, every output within one unit of q per column."""
+    rng = np.random.default_rng(21 + K)
+    N, m = 256, 37
+    stride = (K + 255) // 256 * 64
+    qs = rng.integers(0, 256, N * stride, dtype=np.uint8)
+    h = hip.weights_upload_qk256(qs, N, K, stride)
+    x = (rng.normal(0.3, 1.0, (m, K)) * np.exp(rng.normal(0, 1, (m, 1)))).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    eps = np.float32(1e-5)
+    x64 = x.astype(np.float64)
+    mean_d = x64.sum(1) / K
+    var_d = (x64 * x64).sum(1) / K - mean_d * mean_d
+    mean = mean_d.astype(np.float32)
+    denom = np.sqrt(np.maximum(var_d, 0).astype(np.float32) + eps).astype(np.float32)
+    t = (x - mean[:, None]) * g[None, :]
+    assert t.dtype == np.float32
+    am = (np.abs(t).max(1) / denom).astype(np.float32)
+    be = np.maximum((am.view(np.uint32) >> 23) & 0xFF, 32).astype(np.int64)
+    sc = (np.exp2((13 - (be - 127)).astype(np.float64)).astype(np.float32) / denom).astype(np.float32)
+    inv_s = np.exp2(((be - 127) - 13).astype(np.float64)).astype(np.float32)
+    q = np.rint(t * sc[:, None]).astype(np.int64)
+    assert np.abs(q).max() <= 1 << 14
+    codes = np.stack([(qs.reshape(N, stride) >> (2 * i)) & 3 for i in range(4)], axis=-1).reshape(N, stride * 4)[:, :K]
+    W = np.array([-2, -1, 1, 2], dtype=np.int64)[codes]
+    want = (q @ W.T).astype(np.float32) * inv_s[:, None]
+    slack = np.abs(W).sum(1)[None, :].astype(np.float64) * inv_s[:, None]  # every q one unit off
+    wsb = hip.matmul_workspace_bytes(m, K, 2)
+    ws = torch_.empty(wsb, dtype=torch_.uint8, device="cuda")
+    gd, xd = torch_.from_numpy(g).cuda(), torch_.from_numpy(x).cuda()
+    outs = []
+    for fl in (8, 16):  # BITNET_HIP_FUSE_INT8_DIGITS, BITNET_HIP_FUSE_FP6_DIGITS
+        y = torch_.full((m, N), float("nan"), device="cuda")
+        hip.matmul_fused_dev(h, xd, y, m, ws, wsb, ln_gamma=gd, ln_eps=float(eps), digits=2, flags=fl)
+        torch_.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert np.all(np.abs(got.astype(np.float64) - want) <= slack + 1e-30), float(np.max(np.abs(got - want) / (slack + 1e-30)))
+        assert np.mean(got == want) >= 0.99, float(np.mean(got == want))
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1])  # the two digit forms carry the same integer
+    hip.weights_free(h)
