@@ -1853,6 +1853,135 @@ __global__ __launch_bounds__(256, (TTW >= 4 || EPI) ? 2 : TTW == 2 ? 3 : 4) void
     }
 }
 
+// k_gemm_fp6w (round 5): the same product, operands, k-order per accumulator and results as k_gemm_fp6<4, 4, 1, 0> on a 2 x 2 wave arrangement --
+// wave (wr, wt) owns rows 128 wr .. + 127 (EIGHT row tiles) x tokens 32 wt .. + 31 (two token tiles) of the 256 x 64 workgroup tile, so a B operand read from
+// LDS feeds eight MFMAs instead of four: half the LDS operand bytes per MFMA (the unit an ablation named: EXPERIMENTS 8.8), paid for with twice the weight
+// loads per wave (the two waves of a row half fetch the same 2 KiB pieces: L1 / L2 hits).  128 weight registers (this step's + the next step's) leave no room for a
+// register-staged activation tile: it goes global -> LDS by LDS-DMA (wave w moves lane-group slab g = w: 576 units of 16 bytes = nine 1 KiB pieces, each lane
+// fetching the unit that belongs at its slot), requested a whole K step ahead; weights by buffer loads (visible to hipcc's vmcnt bookkeeping).
+__global__ __launch_bounds__(256, 2) void k_gemm_fp6w(GemmArgs p) {
+    constexpr int RT = 8, TTW = 2, T = 64, kBuf = T * 576;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4, wr = wave >> 1, wt = wave & 1;
+    const int n_tiles = (p.rows + 15) >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {  // one XCD works through consecutive logical ids (k_gemm_mfma explains)
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if ((total & 7) == 0) {
+            const int l = (id & 7) * (total >> 3) + (id >> 3);
+            bx = l % gx;
+            by = l / gx;
+            if (p.wgroup > 0) {
+                const int per = (int)gridDim.y * p.wgroup, grp = l / per, r = l - grp * per;
+                by = r / p.wgroup;
+                bx = grp * p.wgroup + (r - by * p.wgroup);
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_w = gbuf_rsrc(p.tiles4);
+    int wptr[RT];  // scalar byte offsets of this wave's row tiles in the fp4 image
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int t = bx * 16 + wr * 8 + rt;
+        t = t < n_tiles ? t : n_tiles - 1;
+        wptr[rt] = t * p.nblk * 2048;
+    }
+    const uint32_t woff = (uint32_t)lane * 16u;
+    const uint32_t row_bytes = (uint32_t)p.nblk * 576u;
+    const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.planes) + (size_t)by * T * row_bytes + (size_t)wave * 144;  // uniform: slab g = wave of every token's record
+    uint32_t dsrc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = i * 64 + lane, tok = r / 9, k = r - tok * 9;
+        dsrc[i] = (uint32_t)tok * row_bytes + (uint32_t)k * 16u;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    auto stage = [&](int blk, int buf) {
+        const uint8_t *src = abase + (size_t)blk * 576;
+        const unsigned dst = lds0 + (unsigned)buf * kBuf + (unsigned)wave * 9216u;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gdma1k(dsrc[i], src, dst + 1024u * i);
+    };
+    gv4f acc[RT][TTW];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TTW; ++ct) acc[rt][ct] = (gv4f){0.f, 0.f, 0.f, 0.f};
+    v4i wn[2][RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wn[m][rt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, wptr[rt] + m * 1024, 0));
+    stage(0, 0);
+    // (the builtin form: hipcc's own bookkeeping then knows its weight loads have retired and puts no counted wait in front of their first use -- a
+    //  counted wait would, in hardware, also wait for the DMA requests it cannot see)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    const int bread = (g * T + wt * 32 + c) * 144;
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        const uint8_t *bcur = lds + (blk & 1) * kBuf + bread;
+        if (blk + 1 < p.nblk) stage(blk + 1, (blk + 1) & 1);  // (every wave is past the barrier that ended step blk - 1: nobody reads that buffer)
+        v4i a[2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m][rt] = wn[m][rt];
+        {
+            const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) wn[m][rt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, wptr[rt] + n1 * 2048 + m * 1024, 0));
+        }
+        constexpr int NG = TTW * 3;
+        v4i rr[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rr[0][q] = *reinterpret_cast<const v4i *>(bcur + 16 * q);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const int ct = grp / 3, d = grp % 3;
+            if (grp + 1 < NG) {
+                const uint8_t *bp = bcur + ((grp + 1) / 3) * 16 * 144 + ((grp + 1) % 3) * 48;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rr[(grp + 1) & 1][q] = *reinterpret_cast<const v4i *>(bp + 16 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const v4i r0 = rr[grp & 1][0], r1 = rr[grp & 1][1], r2 = rr[grp & 1][2];
+            const gv8i b0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1);
+            const gv8i b1 = __builtin_shufflevector(r1, r2, 2, 3, 4, 5, 6, 7, -1, -1);
+            const int sb = 130 + 5 * d;  // B scale: the digit's weight 2^(3 + 5 d)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[0][rt], a[0][rt], 0, 1, 2, 3, -1, -1, -1, -1), b0, acc[rt][ct], 4, 2, 0,
+                                                                               127, 0, sb);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a[1][rt], a[1][rt], 0, 1, 2, 3, -1, -1, -1, -1), b1, acc[rt][ct], 4, 2, 0,
+                                                                               127, 0, sb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next tile have landed, and the next step's weights
+        asm volatile("" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        const int tok0 = (by * 4 + wt * 2 + tt) * 16;
+        const float is = p.inv_scale[tok0 + c];  // (padding rows: 0)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float val[4][4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[rt][j] = acc[4 * hf + rt][tt][j] * is;
+            store_wave_tiles(p, val, tok0, c, g, bx * 16 + wr * 8 + 4 * hf);
+        }
+    }
+}
+
 // f32 rows -> the f16 chain's first input: xh = f16(gamma * x) (nullable gamma: 1) and the row's (sum, sum of squares) as partial 0
 // of the consumer's LayerNorm statistics.  One workgroup per row; used once per prompt (the embedding rows); every later hand-over is
 // an epilogue of the kernel that produced the rows.
@@ -2156,6 +2285,13 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     g_last_gemm_tile = GemmTileChoice{2, 16 * ttw, 4, 6, rt5 ? 80 : 64, res ? 1 : 0};
     GemmArgs aw = a;
     aw.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false, res ? kFp4GroupBudget : (size_t)3 << 19);  // (the image is twice the bytes per row block)
+    static const int fp6w_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_FP6W"); return e ? atoi(e) : 1; }();
+    if (fp6w_mode && res && ttw == 4 && !rt5 && w.rows % 256 == 0 && (size_t)div_ceil(w.rows, 16) * (w.cols / 256) * 2048 < ((size_t)1 << 31)) {
+        static std::once_flag raised;
+        std::call_once(raised, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_fp6w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        hipLaunchKernelGGL(k_gemm_fp6w, dim3((unsigned)gx0, (unsigned)(q.m_pad / 64)), dim3(256), (size_t)2 * 64 * 576, stream, aw);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(fk, dim3((unsigned)gx0, (unsigned)(q.m_pad / (16 * ttw))), dim3(256), (size_t)2 * ttw * 16 * 576, stream, aw, lut_fp4(w.lut));
     return hipGetLastError();
 }

@@ -189,3 +189,34 @@ def test_build_warns_on_an_unvalidated_hipcc(monkeypatch, capsys):
     monkeypatch.setattr(build, "VALIDATED_HIPCC", "HIP version: 0.0")
     build.warn_if_unvalidated_hipcc()
     assert "hand-counted" in capsys.readouterr().err
+
+
+GEMMFP6W = "_ZN10bitnet_hip11k_gemm_fp6wENS_8GemmArgsE"
+
+
+def test_fp6w_k_loop_mixes_dma_and_tracked_loads_without_a_counted_wait(isa):
+    """k_gemm_fp6w (round 5) stages its activation tile by LDS-DMA (invisible to hipcc's vmcnt bookkeeping) AND loads its weights by buffer loads hipcc
+    does track: a counted `s_waitcnt vmcnt(n > 0)` that hipcc put in front of the weights' first use would, in hardware, also wait for DMA pieces or
+    for part of the NEXT step's weights.  The kernel ends every step with the builtin vmcnt(0), so hipcc knows its loads have retired: the loop must
+    hold that one wait and no other, 9 DMA pieces, 16 weight loads, 96 scaled MFMAs, one barrier, no scratch."""
+    lines, usage = isa["kernels_gemm.hip"]
+    u = usage[GEMMFP6W]
+    assert u["ScratchSize"] == 0 and u["VGPRs"] + u.get("AGPRs", 0) <= 250 and u["Occupancy"] >= 2, u
+    body = body_of(lines, GEMMFP6W)
+    loops = [(a, b) for a, b in inner_loops(body) if sum(t.startswith("v_mfma_scale") for _, _, t in classify(body[a:b + 1])) >= 96]
+    assert len(loops) == 1, loops
+    lo, hi = loops[0]
+    # hipcc rotates this loop: the block that requests the next tile sits BEFORE the header label and is reached by a branch from the loop's end
+    for j in range(lo, hi + 1):
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)\b", body[j])
+        if m:
+            at = next(i for i, l in enumerate(body) if l.startswith(m.group(1) + ":"))
+            lo = min(lo, at)
+    ins = classify(body[lo:hi + 1])
+    assert sum(t.startswith("v_mfma_scale_f32_16x16x128_f8f6f4") for _, _, t in ins) == 96
+    assert sum(t.startswith("global_load_lds_dwordx4") for _, _, t in ins) == 9
+    assert sum(t.startswith("buffer_load_dwordx4") for _, _, t in ins) == 16
+    assert sum("s_barrier" in t for _, _, t in ins) == 1
+    assert not any(t.startswith(("scratch_", "global_store", "buffer_store")) for _, _, t in ins)
+    waits = [t for _, _, t in ins if "vmcnt" in t]
+    assert len(waits) == 1 and "vmcnt(0)" in waits[0], waits
