@@ -551,7 +551,7 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs &p, float (&val)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = gclamp_f16(r[pr][j], sat);
                     gflush_sat(sat);
-                    *reinterpret_cast<sh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;
+                    *reinterpret_cast<sh4 *>(p.yh + (size_t)token * half_rows + ra + 16 * pr) = o;  // (non-temporal: no gain, 257-275 vs 261-291 us same box)
                 }
             }
         } else if ((half_rows & 3) == 0) {
@@ -1922,7 +1922,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp6w(GemmArgs p) {
     const int bread = (g * T + wt * 32 + c) * 144;
     for (int blk = 0; blk < p.nblk; ++blk) {
         const uint8_t *bcur = lds + (blk & 1) * kBuf + bread;
+#if defined(BH_ABLATE) && (BH_ABLATE & 128)
+        if (blk + 1 < p.nblk && p.m == 12345) stage(blk + 1, (blk + 1) & 1);
+#else
         if (blk + 1 < p.nblk) stage(blk + 1, (blk + 1) & 1);  // (every wave is past the barrier that ended step blk - 1: nobody reads that buffer)
+#endif
         v4i a[2][RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1930,6 +1934,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp6w(GemmArgs p) {
             for (int m = 0; m < 2; ++m) a[m][rt] = wn[m][rt];
         {
             const int n1 = blk + 1 < p.nblk ? blk + 1 : p.nblk - 1;
+#if defined(BH_ABLATE) && (BH_ABLATE & 256)
+            if (p.m == 12345)
+#endif
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1977,7 +1984,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_fp6w(GemmArgs p) {
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) val[rt][j] = acc[4 * hf + rt][tt][j] * is;
+#if defined(BH_ABLATE) && (BH_ABLATE & 64)
+            if (val[0][0] == 1234567.f) store_wave_tiles(p, val, tok0, c, g, bx * 16 + wr * 8 + 4 * hf);
+#else
             store_wave_tiles(p, val, tok0, c, g, bx * 16 + wr * 8 + 4 * hf);
+#endif
         }
     }
 }
