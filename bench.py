@@ -414,7 +414,7 @@ def prefill_roofline(hip, dec, cfg, n_tokens: int, digits: int, fmt_qk256: bool,
     alg = 2.0 * n_tokens * 2 * F * K / us / 1e6
     return {"bound": "mfma-f16" if f16 else "mfma-f8f6f4 (fp4 x fp6)" if fp6 else "mfma-i8",
             "kernel": ("k_gemm_f16h + k_gemm_f16a (f16 chain: f16 rows in, no quantiser): LayerNorm after the product -> gate|up -> silu*mul" if chain else
-                       ("k_gemm_f16a" if f16 else "k_gemm_fp6 (resident fp4 weights)" if fp6 else "k_gemm_mfma") + " (+ its row quantiser): LayerNorm -> gate|up -> silu*mul"),
+                       ("k_gemm_f16a" if f16 else "k_gemm_fp6w (2 x 2 waves, resident fp4 weights)" if fp6 and tile.get("resident_fp4") else "k_gemm_fp6" if fp6 else "k_gemm_mfma") + " (+ its row quantiser): LayerNorm -> gate|up -> silu*mul"),
             "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s" if f16 else "TOP/s", "frac": round(achieved / peak, 4),
             "counts": "2 m n k" if f16 else "matrix-core operations issued (2 m n k x 3 base-32 digits)" if fp6 else "matrix-core operations issued (2 m n k x digits)",
             "algorithmic": {"TFLOPs": round(alg, 1), "frac_of_f16_peak": round(alg / MFMA_F16_PEAK_TFLOPS, 4)},
