@@ -2300,6 +2300,7 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     if (fp6w_mode && res && ttw == 4 && !rt5 && w.rows % 256 == 0 && (size_t)div_ceil(w.rows, 16) * (w.cols / 256) * 2048 < ((size_t)1 << 31)) {
         static std::once_flag raised;
         std::call_once(raised, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_fp6w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        g_last_gemm_tile.wave_rows = 128;  // the 2 x 2 arrangement: a wave owns 128 rows x 32 tokens of the 256 x 64 tile
         hipLaunchKernelGGL(k_gemm_fp6w, dim3((unsigned)gx0, (unsigned)(q.m_pad / 64)), dim3(256), (size_t)2 * 64 * 576, stream, aw);
         return hipGetLastError();
     }

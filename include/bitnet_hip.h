@@ -254,6 +254,7 @@ int bitnet_hip_matmul_fused_dev(bitnet_hip_weights_t w, const float *x_dev, floa
 int bitnet_hip_matmul_last_tile(int *digits, int *wave_tokens, int *waves, int *scale_mode);
 /* Output rows per wave of that launch: 64 (four 16-row tiles, 256-row workgroups) or 80 (five: the 320-row workgroups the forms with
  * f32 accumulators take when they need fewer rounds of the chip -- 2560 output rows x 4096 tokens = 512 workgroups, one round);
+ * or 128 (the fp6 x fp4 form's 2 x 2 wave arrangement, k_gemm_fp6w: a wave owns 128 rows x 32 tokens of the 256 x 64 workgroup tile);
  * 0 before the thread's first tiled matmul.  scale_mode 5 = the f16 MFMA on an unscaled matrix, 6 = the fp6 x fp4 form (k_gemm_fp6). */
 int bitnet_hip_matmul_last_wave_rows(void);
 /* 1 when that launch was the fp6 x fp4 form reading its weight operands from the resident fp4 image (below), else 0. */
