@@ -173,3 +173,29 @@ def test_rejected_config_gives_a_dead_decoder_that_refuses_every_call(pkg):
     synth = importlib.import_module("bitnet-rs_amd.synth")
     with pytest.raises(pkg.BitNetHipError, match="multiple of 512"):
         pkg.HostDecoder(synth.ModelConfig(hidden=100, n_layers=1, n_heads=4, n_kv_heads=2, head_dim=128, ffn=256, vocab=64, max_pos=32))
+
+
+def test_integration_md_declares_every_entry_point_for_rust():
+    """INTEGRATION.md section 2 is the `extern "C"` block a reference maintainer pastes into crates/bitnet-kernels/src/rocm/sys.rs: every symbol the
+    header declares must be spelt out there (round 4's review counted 44 of 70), with the argument count of the C prototype
+    (tools/gen_rust_extern.py is the mechanical map both sides are held to)."""
+    import importlib.util
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rust_extern", os.path.join(root, "tools", "gen_rust_extern.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = dict(gen.prototypes(open(os.path.join(root, "include", "bitnet_hip.h")).read()))
+    assert len(want) >= 77
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    have = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (bitnet_hip_[a-z0-9_]+)\(([^;]*?)\)\s*(?:->[^;]*)?;", text, re.S)}
+    missing = sorted(set(want) - set(have))
+    assert not missing, missing
+
+    def n_args(params: str) -> int:
+        return 0 if not params.strip() else params.count(":")
+
+    for name, line in want.items():
+        assert n_args(have[name]) == n_args(line[line.index("(") + 1:line.rindex(")")]), name
