@@ -2107,8 +2107,6 @@ static bool quant_rows_w_applies(const QuantArgs &q) {
 }
 static void launch_quant_rows_w(const QuantArgs &q, bool fp6, hipStream_t stream) {
     if (fp6) {
-        static std::once_flag raised;
-        std::call_once(raised, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quant_rows_w<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024); });
         hipLaunchKernelGGL(k_quant_rows_w<1>, dim3(q.m_pad / 4), dim3(256), (size_t)4 * (size_t)(q.kp / 32) * 80, stream, q);
     } else {
         hipLaunchKernelGGL(k_quant_rows_w<0>, dim3(q.m_pad / 4), dim3(256), 0, stream, q);
@@ -2298,8 +2296,8 @@ static hipError_t launch_gemm_fp6(const Weights &w, const QuantArgs &q, const Ge
     aw.wgroup = gemm_weight_group(gx0, rt5 ? 320 : 256, res ? 2 * w.cols : w.cols, false, res ? kFp4GroupBudget : (size_t)3 << 19);  // (the image is twice the bytes per row block)
     static const int fp6w_mode = [] { const char *e = getenv("BITNET_HIP_GEMM_FP6W"); return e ? atoi(e) : 1; }();
     if (fp6w_mode && res && ttw == 4 && !rt5 && w.rows % 256 == 0 && (size_t)div_ceil(w.rows, 16) * (w.cols / 256) * 2048 < ((size_t)1 << 31)) {
-        static std::once_flag raised;
-        std::call_once(raised, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_fp6w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_fp6w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // (72 KiB of tile buffers; once, thread-safe)
+        if (raised != hipSuccess) return raised;
         g_last_gemm_tile.wave_rows = 128;  // the 2 x 2 arrangement: a wave owns 128 rows x 32 tokens of the 256 x 64 tile
         hipLaunchKernelGGL(k_gemm_fp6w, dim3((unsigned)gx0, (unsigned)(q.m_pad / 64)), dim3(256), (size_t)2 * 64 * 576, stream, aw);
         return hipGetLastError();
