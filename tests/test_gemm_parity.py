@@ -361,7 +361,8 @@ def test_fp6_form_on_the_resident_fp4_image_is_the_expanding_form_bit_for_bit(hi
     yr = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS, ln_gamma=gd, ln_eps=1e-5)  # first use builds the image
     assert hip.matmul_last_tile()["scale_mode"] == 6 and hip.matmul_last_resident_fp4()
     if (rows, m) in ((3840, 4096), (2048, 8130)):  # full 64-token grids of 256-row workgroups: the 2 x 2 wave arrangement (k_gemm_fp6w) -- same bits
-        assert hip.matmul_last_tile()["wave_tokens"] == 64 and hip.matmul_last_wave_rows() == 128
+        import os
+        assert hip.matmul_last_tile()["wave_tokens"] == 64 and hip.matmul_last_wave_rows() == (128 if os.environ.get("BITNET_HIP_GEMM_FP6W", "1") != "0" else 64)
     tiles = -(-rows // 16) * (stride // 64)
     assert hip.weights_device_bytes(h) == b0 + tiles * 2048
     y8 = run_gemm(hip, torch_, h, x, rows, 2, flags=INT8_DIGITS, ln_gamma=gd, ln_eps=1e-5)
@@ -425,6 +426,9 @@ def test_wave_per_row_quantiser_carries_the_documented_integer(hip, torch_, K):
     operation.  Every product and partial sum behind the quantiser is an exact integer, so the launch must give f32(W q) * 2^(E - 13)
     EXACTLY wherever the model's q is the kernel's; the f64 statistics may be added up in another order (a mean one f32 ulp off moves a
     handful of q by one unit), hence: at least 99 % of the outputs bit-equal, every output within one unit of q per column."""
+    import os
+    if os.environ.get("BITNET_HIP_QUANT_W", "1") == "0":
+        pytest.skip("the workgroup-per-row quantiser divides per element: another (equally valid) integer in rare ties")
     rng = np.random.default_rng(21 + K)
     N, m = 256, 37
     stride = (K + 255) // 256 * 64
