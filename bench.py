@@ -398,7 +398,7 @@ def prefill_roofline(hip, dec, cfg, n_tokens: int, digits: int, fmt_qk256: bool,
         form["flags"] = 1 | 16  # BITNET_HIP_FUSE_FP6_DIGITS: the form the decoder's prompt forward takes for q|k|v and gate|up of an unscaled model (resident fp4 image)
     launch()
     stream.synchronize()
-    tile = dict(hip.matmul_last_tile(), resident_fp4=hip.matmul_last_resident_fp4())
+    tile = dict(hip.matmul_last_tile(), wave_rows=hip.matmul_last_wave_rows(), resident_fp4=hip.matmul_last_resident_fp4())  # (wave_rows 128: the fp6 form's 2 x 2 wave arrangement)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
