@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(256, (TTW >= 4 || EPI) ? 2 : TTW == 2 ? 3 : 4) void
 
 // k_gemm_fp6w (round 5): the same product, operands, k-order per accumulator and results as k_gemm_fp6<4, 4, 1, 0> on a 2 x 2 wave arrangement --
 // wave (wr, wt) owns rows 128 wr .. + 127 (EIGHT row tiles) x tokens 32 wt .. + 31 (two token tiles) of the 256 x 64 workgroup tile, so a B operand read from
-// LDS feeds eight MFMAs instead of four: half the LDS operand bytes per MFMA (the unit an ablation named: EXPERIMENTS 8.8), paid for with twice the weight
+// LDS feeds eight MFMAs instead of four: half the LDS operand bytes per MFMA (the unit an ablation named: EXPERIMENTS 8.7), paid for with twice the weight
 // loads per wave (the two waves of a row half fetch the same 2 KiB pieces: L1 / L2 hits).  128 weight registers (this step's + the next step's) leave no room for a
 // register-staged activation tile: it goes global -> LDS by LDS-DMA (wave w moves lane-group slab g = w: 576 units of 16 bytes = nine 1 KiB pieces, each lane
 // fetching the unit that belongs at its slot), requested a whole K step ahead; weights by buffer loads (visible to hipcc's vmcnt bookkeeping).

@@ -1,6 +1,6 @@
 """Developer tool: time k_gemm_fp6w (gate|up shape, 4096 tokens, LayerNorm in, silu * up as f16 rows out; quantiser included) with parts compiled out
 (BH_ABLATE bit mask: 64 no epilogue stores (and no silu arithmetic), 128 no LDS-DMA staging after the first tile, 256 no weight loads after the first step).
-Results are wrong by construction; only the time matters.   BH_ABLATE=n python bitnet-rs_amd/build.py; python tools/ablate_fp6w.py n   (EXPERIMENTS 8.9)"""
+Results are wrong by construction; only the time matters.   BH_ABLATE=n python bitnet-rs_amd/build.py; python tools/ablate_fp6w.py n   (EXPERIMENTS 8.7)"""
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
