@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (GPU box): counter passes over k_gemm_f16a (gate|up shape), one rocprofv3 run per counter group: tools/pmc_f16a.sh [i2s|qk256]
+# Developer tool (GPU box): counter passes over the f16 chain's gate|up launch (k_gemm_f16h + k_gemm_f16a), one rocprofv3 run per counter group: tools/pmc_f16a.sh [i2s|qk256]
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -16,8 +16,9 @@ import csv, glob, collections, sys
 tot = collections.defaultdict(lambda: [0, 0])
 for f in glob.glob(sys.argv[1] + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_gemm_f16a" in r["Kernel_Name"]:
-            t = tot[r["Counter_Name"]]; t[0] += float(r["Counter_Value"]); t[1] += 1
-for k, (v, n) in sorted(tot.items()):
-    print(f"{k:32s} {v / n:16.0f} per launch ({n} launches)")
+        for fam in ("k_gemm_f16h", "k_gemm_f16a"):  # (round 5: the wide launches run k_gemm_f16h on their whole rounds + k_gemm_f16a on the rest)
+            if fam in r["Kernel_Name"]:
+                t = tot[(fam, r["Counter_Name"])]; t[0] += float(r["Counter_Value"]); t[1] += 1
+for (fam, k), (v, n) in sorted(tot.items()):
+    print(f"{fam:12s} {k:32s} {v / n:16.0f} per launch ({n} launches)")
 PY
