@@ -21,6 +21,14 @@
 //                  tiles are the GEMV's 1-KiB lane-ordered tiles, straight into registers.
 // Weights are read once per 32*TTW tokens (2 bits each: cheap); the int8 activation tile is
 // the larger stream and is shared by the 4 row-waves through LDS.
+//
+// Later forms in this file (each explained at its definition; DESIGN.md 4.2 is the map):
+//   k_gemm_f16a / k_gemm_f16h   BitNet32-F16 (and the hybrid o / down of QK256) on v_mfma_f32_16x16x32_f16: f16 rows handed from epilogue to epilogue,
+//                               LayerNorm after the product (f16_chain_epilogue, ChainLnStats); f16h = 64 x 128 wave tile for the wide launches
+//   k_gemm_fp6 / k_gemm_fp6w    the 2-digit product as three base-32 fp6 digits x fp4 weights on v_mfma_scale_f32_16x16x128_f8f6f4 (bit-identical to the
+//                               int8 planes); resident fp4 image (k_retile_fp4); fp6w = 2 x 2 wave arrangement, LDS-DMA staging, buffer-loaded weights
+//   k_quant_rows_w              the 2-digit quantiser with one wave per row (long launches of rows <= 2560 columns)
+//   QB32 (k_rows_to_qb32, qb32_pack_unit, k_gemm_fp6<.., EPI = 1>)   producer-quantised block-scaled rows: no quantiser launch (opt-in)
 #include <mutex>
 #include <unordered_set>
 
