@@ -342,7 +342,7 @@ def test_fp6_form_is_the_int8_two_digit_product_bit_for_bit(hip, oracle, torch_,
 FP6_EXPAND = 32  # BITNET_HIP_FUSE_FP6_EXPAND
 
 
-@pytest.mark.parametrize("rows,cols,m", [(2560, 2560, 4096), (512, 1024, 70), (13824, 2560, 300), (336, 512, 33), (3840, 2560, 4096), (2048, 512, 8130)])
+@pytest.mark.parametrize("rows,cols,m", [(2560, 2560, 4096), (512, 1024, 70), (13824, 2560, 300), (336, 512, 33), (3840, 2560, 4096), (2048, 512, 8130), (13824, 2560, 4096)])
 def test_fp6_form_on_the_resident_fp4_image_is_the_expanding_form_bit_for_bit(hip, torch_, rows, cols, m):
     """Round 5: k_gemm_fp6<.., RES = 1> loads its A operands from the resident fp4 image (k_retile_fp4: exactly the nibbles expand16_fp4
     produces, stored once) -- the SAME operands, so the same bits as the in-loop expansion (BITNET_HIP_FUSE_FP6_EXPAND) and as the int8
@@ -360,7 +360,7 @@ def test_fp6_form_on_the_resident_fp4_image_is_the_expanding_form_bit_for_bit(hi
     assert hip.weights_device_bytes(h) == b0  # the expanding form builds nothing
     yr = run_gemm(hip, torch_, h, x, rows, 2, flags=FP6_DIGITS, ln_gamma=gd, ln_eps=1e-5)  # first use builds the image
     assert hip.matmul_last_tile()["scale_mode"] == 6 and hip.matmul_last_resident_fp4()
-    if (rows, m) in ((3840, 4096), (2048, 8130)):  # full 64-token grids of 256-row workgroups: the 2 x 2 wave arrangement (k_gemm_fp6w) -- same bits
+    if (rows, m) in ((3840, 4096), (2048, 8130), (13824, 4096)):  # (the last: the benchmarked gate|up instance)  # full 64-token grids of 256-row workgroups: the 2 x 2 wave arrangement (k_gemm_fp6w) -- same bits
         import os
         assert hip.matmul_last_tile()["wave_tokens"] == 64 and hip.matmul_last_wave_rows() == (128 if os.environ.get("BITNET_HIP_GEMM_FP6W", "1") != "0" else 64)
     tiles = -(-rows // 16) * (stride // 64)
